@@ -1,0 +1,29 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MATRICES = ["matrix", "matrix2", "matrix3", "matrix4", "matrix5"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def mtx(name):
+    return os.path.join(GOLDEN, name + ".mtx")
+
+
+@pytest.fixture(params=MATRICES)
+def matrix_name(request):
+    return request.param

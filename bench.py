@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the SpMV hot path (BASELINE.json metric).
+
+A "step" is one float (+,x) CSR SpMV  out = A x  (alpha=1, beta=0, the
+configuration of the reference's app/spmv.cpp:117-120) over the whole synthetic
+matrix, inputs resident in HBM.  Default workload = BASELINE.json configs[4],
+the one the target is quoted on: power-law 10 M rows / 200 M non-zeros
+(SURVEY.md 8d generator, seed 0x5EED1000), which fits one GPU.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the SAME matrix
+is row-sharded into nnz-balanced contiguous row ranges (strong scaling); x is
+replicated; single-shot SpMV needs no collective (each rank owns its slice of y).
+value = 2 * nnz_total * K / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0 with the driver's contract keys plus
+  roofline     : algorithmic bytes of this rank's launch / its average device
+                 time (HIP events on the launch stream), vs 8 TB/s HBM peak
+  cpu_baseline : the oracle's single-thread restatement of the reference gold
+                 dot loop (inc/spmv_gold.h:17-26) timed on this host (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (kind, rows, nnz, description)
+    "powerlaw-10M-200M": ("powerlaw", 10_000_000, 200_000_000,
+                          "power-law rows P(d)~d^-2.1 on [1,1e6], uniform columns, 10M x 10M, 200M nnz, seed 0x5EED1000"),
+    "rmat-23": ("rmat", 1 << 23, 16 << 23, "Graph500 R-MAT scale 23, edge factor 16, permuted ids, seed 0x5EED0023"),
+    "scircuit-like": ("scircuit", 170_998, 958_936, "scircuit-shaped stand-in, seed 0x5EED5C1C"),
+}
+
+
+def make_workload(name, rows=None, nnz=None):
+    from sparseharness_amd import hostlib as H
+    kind, r, z, desc = WORKLOADS[name]
+    if kind == "powerlaw":
+        r, z = rows or r, nnz or z
+        rp, ci, va = H.powerlaw(r, z)
+        if rows or nnz:
+            desc += f" [overridden to {r} rows / {z} nnz]"
+    elif kind == "rmat":
+        scale = int(np.log2(rows)) if rows else 23
+        rp, ci, va = H.rmat(scale)
+        r, z = 1 << scale, int(rp[-1])
+    else:
+        rp, ci, va = H.scircuit_like()
+    return rp, ci, va, r, desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="powerlaw-10M-200M", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=None, help="override size (testing only; makes the number non-headline)")
+    ap.add_argument("--nnz", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (corrected); echoed into roofline.traffic")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sparseharness_amd import partition
+    from sparseharness_amd.engine import PLUS_TIMES_F32, Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the SpMV engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    t_gen = time.time()
+    rp, ci, va, n, desc = make_workload(args.workload, args.rows, args.nnz)
+    nnz_total = int(rp[-1])
+    t_gen = time.time() - t_gen
+
+    # ---- shard: nnz-balanced contiguous row ranges
+    bounds = partition.row_bounds(rp, world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    s_rp, s_ci, s_va = partition.take_rows(rp, ci, va, r0, r1)
+    s_rows, s_nnz = r1 - r0, int(s_rp[-1])
+
+    stream = torch.cuda.current_stream()
+    eng = Engine(local_rank, stream=stream.cuda_stream)
+    A = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va)
+    x_host = (1 + np.arange(n) % 7).astype(np.float32)  # a wrong gather cannot pass
+    x_t = torch.from_numpy(x_host).cuda()
+    out_t = torch.zeros(max(s_rows, 1), dtype=torch.float32, device="cuda")
+    x = eng.wrap(x_t.data_ptr(), n)
+    out = eng.wrap(out_t.data_ptr(), s_rows)
+
+    def step():
+        eng.spmv(PLUS_TIMES_F32, A, x, None, 1.0, 0.0, out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms_per_launch = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # ---- parity of what was just timed (this rank's rows), against the oracle's gold
+    y = out_t.cpu().numpy()[:s_rows]
+    from oracle import oracle as O   # checker + reported CPU baseline only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        gold = np.empty(n, np.float32)
+        times = []
+        for _ in range(3):
+            tc = time.perf_counter()
+            O.gold_dot(rp, ci, va, x_host, 1.0, out=gold)
+            times.append(time.perf_counter() - tc)
+        tmed = sorted(times)[1]
+        cpu = {"value": round(2.0 * nnz_total / tmed / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+               "sample": f"full {args.workload} matrix ({nnz_total} nnz), median of 3 single-thread runs of the "
+                         f"gold dot loop restatement (oracle_gold_dot_f32), {tmed:.3f} s each",
+               "host_cpus": os.cpu_count()}
+        want = gold
+    else:
+        want = O.gold_dot(s_rp, s_ci, s_va, x_host, 1.0)
+    tol = 1e-5 * np.maximum(1.0, np.abs(want.astype(np.float64)))
+    bad = int((np.abs(y.astype(np.float64) - want.astype(np.float64)) > tol).sum())
+    parity = {"checked_rows": int(s_rows), "mismatches_rel_1e-5": bad,
+              "bit_exact_rows": int((y == want).sum())}
+
+    alg_bytes = A.algorithmic_bytes(reads_y=False)
+    achieved = alg_bytes / (dev_ms_per_launch * 1e-3) / 1e9
+    result = {
+        "metric": "spmv_gflops", "value": round(2.0 * nnz_total * args.steps / wall / 1e9, 3), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "rows": n, "nnz": nnz_total, "semiring": "plus-times f32",
+                   "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} nnz-balanced row ranges, x replicated"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": args.traffic_bytes,
+                     "kernel": "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)",
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
+                     "rank": rank, "rank_nnz": s_nnz},
+        "cpu_baseline": cpu,
+        "parity": parity,
+        "gen_seconds": round(t_gen, 2), "device": eng.device_name,
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if bad:
+        raise SystemExit(f"parity check failed on rank {rank}: {bad} rows outside 1e-5")
+
+
+if __name__ == "__main__":
+    main()

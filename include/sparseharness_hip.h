@@ -1,0 +1,171 @@
+/* sparseharness_hip.h -- C ABI of the MI355X-native CSR SpMV engine.
+ *
+ * This is the drop-in boundary for sparseharness's hot path.  The reference
+ * has no FFI: its apps subclass Harness<TimingType,SemiRingType>
+ * (inc/harness.h:11) and the "operator" is an OpenCL source string bound
+ * positionally.  The entry points below are what that class's protected
+ * helpers bind to once OpenCL is replaced by HIP; each one names the
+ * reference interface it replaces (paths relative to the reference root).
+ * The source-compatible C++ mirror that calls them lives in
+ * sparseharness_amd/host/inc/harness.h; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every call returns int: SH_OK (0) or a negative SH_E* code; nothing
+ *     exits the process (the reference's checkCLError -> exit(1),
+ *     inc/opencl_utils.h:15-23, is re-created by the C++ mirror on top);
+ *   - sh_last_error() gives the message of the last failing call on an engine
+ *     (or of the last failing sh_engine_create when passed NULL);
+ *   - the caller owns host memory, the engine owns device memory until the
+ *     matching *_free / sh_engine_destroy;
+ *   - one engine per host thread; an engine owns (or borrows) ONE hipStream_t
+ *     and all its work is ordered on it (the reference has one in-order
+ *     queue, inc/harness.h:79-80);
+ *   - all vector/matrix elements are 4 bytes: float for SH_PLUS_TIMES_F32 and
+ *     SH_MIN_PLUS_F32, int32 for SH_OR_AND_I32;
+ *   - there is NO CPU fallback: without a HIP device sh_engine_create fails
+ *     with SH_ENODEVICE.
+ */
+#ifndef SPARSEHARNESS_HIP_H_
+#define SPARSEHARNESS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SH_ABI_VERSION 1
+
+enum {
+  SH_OK = 0,
+  SH_EINVAL = -1,    /* bad argument (null pointer, negative size, bad enum) */
+  SH_ENODEVICE = -2, /* no usable HIP device / ordinal out of range */
+  SH_EHIP = -3,      /* a HIP runtime call failed; see sh_last_error */
+  SH_ENOMEM = -4,    /* host or device allocation failed */
+  SH_ESHAPE = -5     /* operand sizes do not match the matrix */
+};
+
+/* Semirings = the user functions of example/{spmv,sssp,bfs}/kernel5.json:3
+ *   PLUS_TIMES: mult l*r, add x+y, identity 0,       out = dot*alpha + y*beta
+ *   MIN_PLUS:   mult |a|+|b|, add min(|a|,|b|), identity FLT_MAX,
+ *               out = min(|dot|+|alpha|, |y|+|beta|)
+ *   OR_AND:     mult (a!=0)&&(b!=0), add ||, identity 0,
+ *               out = (dot&&alpha) || (y&&beta)                         */
+typedef enum {
+  SH_PLUS_TIMES_F32 = 0,
+  SH_MIN_PLUS_F32 = 1,
+  SH_OR_AND_I32 = 2
+} sh_semiring;
+
+/* Launch geometry handed down from the run-file: replaces class Run
+ * (inc/run.h:9-32) as consumed by Harness::executeKernel
+ * (inc/harness.h:153-158).  The native kernels derive their grid from the
+ * matrix schedule; local[0] (64..1024, multiple of 64) is honoured as the
+ * workgroup size where the kernel allows it, everything else is recorded and
+ * ignored.  May be NULL. */
+typedef struct sh_launch {
+  uint64_t global[3];
+  uint64_t local[3];
+} sh_launch;
+
+typedef struct sh_engine sh_engine;
+typedef struct sh_csr sh_csr;
+typedef struct sh_vec sh_vec;
+
+/* ---- engine: replaces Harness::Harness (inc/harness.h:13-82) ------------ */
+int sh_abi_version(void);
+/* Number of HIP devices (0 when none / no driver).  Never fails. */
+int sh_device_count(void);
+/* Create an engine on HIP device `device_ordinal` with its own stream. */
+int sh_engine_create(int device_ordinal, sh_engine **out);
+/* Same, but all work is enqueued on the caller's hipStream_t (e.g. the
+ * current PyTorch stream) instead of an engine-owned one. */
+int sh_engine_create_on_stream(int device_ordinal, void *hip_stream, sh_engine **out);
+int sh_engine_destroy(sh_engine *e);
+/* Replaces Harness::getDeviceName (inc/harness.h:100-107). */
+int sh_engine_device_name(sh_engine *e, char *buf, size_t buflen);
+/* Replaces deviceGetMaxAllocSize (inc/opencl_utils.h:216-226): free device bytes. */
+int sh_engine_max_alloc(sh_engine *e, uint64_t *bytes);
+/* Block until everything enqueued on the engine's stream has finished
+ * (the reference waits after every enqueue, inc/harness.h:159). */
+int sh_engine_synchronize(sh_engine *e);
+const char *sh_last_error(const sh_engine *e);
+
+/* ---- matrix: replaces SparseMatrix::cl_encode (src/sparse_matrix.cpp:122-399)
+ *      + the two createAndUploadGlobalArg calls of Harness::allocateBuffers
+ *      (inc/harness.h:201-205).  Takes the CSR view of the reference's row
+ *      structure (row r = ellpackMatrix[r], stored order kept).  `val` is
+ *      float[nnz] or int32[nnz] bit patterns.  Builds the device-side launch
+ *      schedule (row blocks, long-row segments).  col_idx entries outside
+ *      [0, cols) are legal and read as the semiring identity
+ *      (bounds ladder of kernel5.json:3). */
+int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
+                  const int32_t *row_ptr, const int32_t *col_idx, const void *val,
+                  sh_csr **out);
+int sh_csr_free(sh_engine *e, sh_csr *m);
+int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
+/* Algorithmic bytes of one SpMV over this matrix:
+ * 8*nnz + 4*(rows+1) + 4*cols + 4*rows [+ 4*rows if y is read]. */
+int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
+
+/* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /
+ *      writeToGlobalArg / fillGlobalArg / readFromGlobalArg
+ *      (inc/harness.h:266-391) for x, y, output ------------------------- */
+int sh_vec_alloc(sh_engine *e, int64_t n, sh_vec **out);
+/* Wrap device memory owned by someone else (e.g. a torch tensor); never freed
+ * by the engine. */
+int sh_vec_wrap(sh_engine *e, void *device_ptr, int64_t n, sh_vec **out);
+int sh_vec_free(sh_engine *e, sh_vec *v);
+int sh_vec_upload(sh_engine *e, sh_vec *v, const void *host, int64_t n);   /* blocking */
+int sh_vec_download(sh_engine *e, const sh_vec *v, void *host, int64_t n); /* blocking */
+int sh_vec_fill(sh_engine *e, sh_vec *v, uint32_t pattern32);              /* async   */
+int sh_vec_copy(sh_engine *e, sh_vec *dst, const sh_vec *src);             /* async   */
+int64_t sh_vec_len(const sh_vec *v);
+void *sh_vec_device_ptr(const sh_vec *v);
+
+/* ---- the hot path: replaces Harness::executeKernel (inc/harness.h:149-195)
+ *      running a Lift kernel (example/<algo>/kernel*.json:3):
+ *        out[r] = epilogue( (+)_j ( x[col_j] (x) val_j ), alpha, y[r], beta )
+ *      alpha/beta point to one element of the semiring's type.  y may be NULL
+ *      when the epilogue does not read it (PLUS_TIMES or OR_AND with beta==0).
+ *      out must not alias x.  If kernel_ns != NULL the call waits and returns
+ *      the device time of the launch(es) in ns (hipEvent START->STOP, as the
+ *      reference's CL_PROFILING_COMMAND_START/END, inc/harness.h:183-194);
+ *      if NULL the call only enqueues. */
+int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x,
+            const sh_vec *y, const void *alpha, const void *beta, sh_vec *out,
+            const sh_launch *launch, uint64_t *kernel_ns);
+
+/* ---- iterative apps: replaces the do/while of HarnessSSSP::executeRun +
+ *      should_terminate_iteration (app/sssp.cpp:97-176) and the BFS twin
+ *      (app/bfs.cpp:94-174) with an on-device loop: the convergence test is
+ *      fused into the kernel epilogue (float: |in-out| < delta, int: ==) and
+ *      only one flag word per iteration crosses PCIe.
+ *        launch k: out = kernel(in, y); y aliases in after launch 0.
+ *      x holds x0 on entry and the final vector on return (the buffer the
+ *      reference's `input` pointer designates after its last swap); y0 is
+ *      read by launch 0 only; scratch is clobbered.  *iters counts launches
+ *      including the confirming one; max_iters bounds non-terminating graphs
+ *      (TODO.md:7-8).  ns_per_iter (may be NULL, capacity max_iters) receives
+ *      each launch's device time; total_ns their sum (MULTI_ITERATION_SUM,
+ *      app/sssp.cpp:77-84). */
+int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x,
+               const sh_vec *y0, sh_vec *scratch, const void *alpha,
+               const void *beta, double delta, int32_t max_iters,
+               const sh_launch *launch, int32_t *iters, int32_t *converged,
+               uint64_t *ns_per_iter, uint64_t *total_ns);
+
+/* One iteration step for callers that drive the loop themselves (the
+ * multi-GPU driver): out = kernel(x, y) and *changed_flag (device int32,
+ * may be NULL) is set to 1 if any row fails the convergence test against
+ * `x`.  x/out may address a longer (replicated) vector: row r of this matrix
+ * compares x[out_row_offset + r] with out[r].  Enqueue only. */
+int sh_spmv_step(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x,
+                 const sh_vec *y, const void *alpha, const void *beta, sh_vec *out,
+                 int64_t x_row_offset, double delta, int32_t *changed_flag_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEHARNESS_HIP_H_ */

@@ -1,0 +1,85 @@
+"""ctypes declarations for the C ABI in include/sparseharness_hip.h.
+
+The shared library is built in-tree by sparseharness_amd/csrc/Makefile
+(hipcc --offload-arch=gfx950).  There is no fallback of any kind: if the
+library is missing this module raises, and if no HIP device is present
+`sh_engine_create` fails with SH_ENODEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparseharness_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SH_OK, SH_EINVAL, SH_ENODEVICE, SH_EHIP, SH_ENOMEM, SH_ESHAPE = 0, -1, -2, -3, -4, -5
+PLUS_TIMES_F32, MIN_PLUS_F32, OR_AND_I32 = 0, 1, 2
+
+
+class sh_launch(C.Structure):
+    _fields_ = [("global_", C.c_uint64 * 3), ("local", C.c_uint64 * 3)]
+
+
+_vp, _i32, _i64, _u64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes): one entry per function declared in the header
+# (tests/test_abi.py checks this table against include/sparseharness_hip.h).
+SIGNATURES = {
+    "sh_abi_version": (_int, []),
+    "sh_device_count": (_int, []),
+    "sh_engine_create": (_int, [_int, _pp]),
+    "sh_engine_create_on_stream": (_int, [_int, _vp, _pp]),
+    "sh_engine_destroy": (_int, [_vp]),
+    "sh_engine_device_name": (_int, [_vp, C.c_char_p, C.c_size_t]),
+    "sh_engine_max_alloc": (_int, [_vp, C.POINTER(_u64)]),
+    "sh_engine_synchronize": (_int, [_vp]),
+    "sh_last_error": (C.c_char_p, [_vp]),
+    "sh_csr_upload": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),
+    "sh_csr_free": (_int, [_vp, _vp]),
+    "sh_csr_dims": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "sh_csr_algorithmic_bytes": (_int, [_vp, _int, C.POINTER(_u64)]),
+    "sh_vec_alloc": (_int, [_vp, _i64, _pp]),
+    "sh_vec_wrap": (_int, [_vp, _vp, _i64, _pp]),
+    "sh_vec_free": (_int, [_vp, _vp]),
+    "sh_vec_upload": (_int, [_vp, _vp, _vp, _i64]),
+    "sh_vec_download": (_int, [_vp, _vp, _vp, _i64]),
+    "sh_vec_fill": (_int, [_vp, _vp, C.c_uint32]),
+    "sh_vec_copy": (_int, [_vp, _vp, _vp]),
+    "sh_vec_len": (_i64, [_vp]),
+    "sh_vec_device_ptr": (_vp, [_vp]),
+    "sh_spmv": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(sh_launch), C.POINTER(_u64)]),
+    "sh_iterate": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i32,
+                          C.POINTER(sh_launch), C.POINTER(_i32), C.POINTER(_i32),
+                          C.POINTER(_u64), C.POINTER(_u64)]),
+    "sh_spmv_step": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_double, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", CSRC]
+    if force:
+        args.insert(1, "-B")
+    subprocess.check_call(args)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). "
+            "sparseharness_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

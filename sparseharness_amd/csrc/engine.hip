@@ -1,0 +1,560 @@
+// engine.hip -- implementation of the C ABI declared in
+// include/sparseharness_hip.h: a thin hipMalloc / hipMemcpyAsync / hipStream
+// layer (replacing the reference's OpenCL context + CLMemoryManager,
+// inc/harness.h:13-82, inc/cl_memory_manager.h:6-29) plus the launch logic of
+// the native CSR SpMV kernels (kernels.hip.h).
+//
+// No CPU fallback: every compute entry point needs a live HIP device.
+#include "../../include/sparseharness_hip.h"
+#include "kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace sh;
+
+struct sh_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int32_t *d_flags = nullptr;   // per-iteration convergence flags
+  int32_t n_flags = 0;
+  int32_t *h_flag = nullptr;    // pinned
+  char name[256] = {0};
+  std::string err;
+};
+
+struct sh_csr {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  int32_t *d_row_ptr = nullptr, *d_col = nullptr;
+  uint32_t *d_val = nullptr;
+  int32_t *d_blk_row = nullptr;
+  int32_t n_stream = 0;
+  LongSeg *d_segs = nullptr;
+  int32_t n_segs = 0;
+  LongRow *d_long = nullptr;
+  int32_t n_long = 0;
+  uint32_t *d_partial = nullptr;
+};
+
+struct sh_vec {
+  void *d = nullptr;
+  int64_t n = 0;
+  bool owned = false;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sh_engine *e, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e)
+    e->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                        \
+  do {                                                                          \
+    hipError_t _r = (call);                                                     \
+    if (_r != hipSuccess)                                                       \
+      return fail((e), _r == hipErrorOutOfMemory ? SH_ENOMEM : SH_EHIP,         \
+                  "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r),        \
+                  __FILE__, __LINE__);                                          \
+  } while (0)
+
+extern "C" {
+
+int sh_abi_version(void) { return SH_ABI_VERSION; }
+
+int sh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+const char *sh_last_error(const sh_engine *e) {
+  return e ? e->err.c_str() : g_create_err.c_str();
+}
+
+static int engine_create(int device, void *stream, bool borrow, sh_engine **out) {
+  if (!out)
+    return fail(nullptr, SH_EINVAL, "sh_engine_create: out is NULL");
+  *out = nullptr;
+  int n = sh_device_count();
+  if (n <= 0)
+    return fail(nullptr, SH_ENODEVICE,
+                "no HIP device available: the sparseharness HIP engine has no CPU fallback");
+  if (device < 0 || device >= n)
+    return fail(nullptr, SH_ENODEVICE, "device ordinal %d out of range [0,%d)", device, n);
+  sh_engine *e = new (std::nothrow) sh_engine();
+  if (!e)
+    return fail(nullptr, SH_ENOMEM, "out of host memory");
+  e->device = device;
+  hipError_t r = hipSetDevice(device);
+  if (r == hipSuccess) {
+    if (borrow) {
+      e->stream = (hipStream_t)stream;
+    } else {
+      r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+      e->own_stream = true;
+    }
+  }
+  if (r == hipSuccess) r = hipEventCreate(&e->ev0);
+  if (r == hipSuccess) r = hipEventCreate(&e->ev1);
+  if (r == hipSuccess) r = hipHostMalloc((void **)&e->h_flag, 64, hipHostMallocDefault);
+  hipDeviceProp_t prop;
+  if (r == hipSuccess) r = hipGetDeviceProperties(&prop, device);
+  if (r != hipSuccess) {
+    int rc = fail(nullptr, SH_EHIP, "engine init failed: %s", hipGetErrorString(r));
+    delete e;
+    return rc;
+  }
+  snprintf(e->name, sizeof e->name, "%s (%s)", prop.name, prop.gcnArchName);
+  *out = e;
+  return SH_OK;
+}
+
+int sh_engine_create(int device_ordinal, sh_engine **out) {
+  return engine_create(device_ordinal, nullptr, false, out);
+}
+int sh_engine_create_on_stream(int device_ordinal, void *hip_stream, sh_engine **out) {
+  return engine_create(device_ordinal, hip_stream, true, out);
+}
+
+int sh_engine_destroy(sh_engine *e) {
+  if (!e)
+    return SH_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  if (e->d_flags) (void)hipFree(e->d_flags);
+  if (e->h_flag) (void)hipHostFree(e->h_flag);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return SH_OK;
+}
+
+int sh_engine_device_name(sh_engine *e, char *buf, size_t buflen) {
+  if (!e || !buf || buflen == 0)
+    return fail(e, SH_EINVAL, "sh_engine_device_name: bad argument");
+  snprintf(buf, buflen, "%s", e->name);
+  return SH_OK;
+}
+
+int sh_engine_max_alloc(sh_engine *e, uint64_t *bytes) {
+  if (!e || !bytes)
+    return fail(e, SH_EINVAL, "sh_engine_max_alloc: bad argument");
+  size_t fr = 0, tot = 0;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemGetInfo(&fr, &tot));
+  *bytes = fr;
+  return SH_OK;
+}
+
+int sh_engine_synchronize(sh_engine *e) {
+  if (!e)
+    return SH_EINVAL;
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return SH_OK;
+}
+
+// ---------------------------------------------------------------- matrix
+// Launch schedule: greedy packing of consecutive rows into stream blocks
+// (<= NNZ_BLK entries counted from the 16-byte-aligned start, <= ROWS_BLK
+// rows); rows that do not fit alone become long rows cut into SEG_NNZ pieces.
+static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t> &blk_row,
+                           std::vector<int32_t> &blk_flags, std::vector<LongSeg> &segs,
+                           std::vector<LongRow> &longs) {
+  // blk_row holds the row boundaries of stream blocks only; long rows are
+  // excluded by closing the current block before them (a stream block never
+  // spans a long row), so a parallel list of (r0, r1) pairs is kept instead.
+  (void)blk_flags;
+  int64_t r = 0;
+  while (r < rows) {
+    const int64_t s = rp[r];
+    const int64_t base = s & ~int64_t(3);
+    if ((int64_t)rp[r + 1] - base > NNZ_BLK) {
+      // long row
+      LongRow lr;
+      lr.row = (int32_t)r;
+      lr.slot0 = (int32_t)segs.size();
+      lr.pad = 0;
+      int32_t k = 0;
+      for (int64_t p = s; p < rp[r + 1]; p += SEG_NNZ, k++) {
+        LongSeg sg;
+        sg.row = (int32_t)r;
+        sg.s = (int32_t)p;
+        sg.e = (int32_t)std::min<int64_t>(p + SEG_NNZ, rp[r + 1]);
+        sg.slot = lr.slot0 + k;
+        segs.push_back(sg);
+      }
+      lr.nslots = k;
+      longs.push_back(lr);
+      r++;
+      continue;
+    }
+    int64_t r1 = r + 1;
+    while (r1 < rows && r1 - r < ROWS_BLK && (int64_t)rp[r1 + 1] - base <= NNZ_BLK)
+      r1++;
+    blk_row.push_back((int32_t)r);
+    blk_row.push_back((int32_t)r1);
+    r = r1;
+  }
+}
+
+int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
+                  const int32_t *col_idx, const void *val, sh_csr **out) {
+  if (!e || !out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_idx || !val)))
+    return fail(e, SH_EINVAL, "sh_csr_upload: bad argument");
+  if (rows > INT32_MAX - 1 || cols > INT32_MAX || nnz > INT32_MAX - 8)
+    return fail(e, SH_EINVAL, "sh_csr_upload: sizes exceed int32 indexing (shard the matrix)");
+  if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
+    return fail(e, SH_ESHAPE, "sh_csr_upload: row_ptr[0]=%d row_ptr[rows]=%d, nnz=%lld", row_ptr[0],
+                row_ptr[rows], (long long)nnz);
+  *out = nullptr;
+  HIP_TRY(e, hipSetDevice(e->device));
+  sh_csr *m = new (std::nothrow) sh_csr();
+  if (!m)
+    return fail(e, SH_ENOMEM, "out of host memory");
+  m->rows = rows; m->cols = cols; m->nnz = nnz;
+
+  std::vector<int32_t> pairs, unused;
+  std::vector<LongSeg> segs;
+  std::vector<LongRow> longs;
+  for (int64_t r = 0; r < rows; r++)
+    if (row_ptr[r + 1] < row_ptr[r]) {
+      delete m;
+      return fail(e, SH_ESHAPE, "sh_csr_upload: row_ptr not monotone at row %lld", (long long)r);
+    }
+  build_schedule(rows, row_ptr, pairs, unused, segs, longs);
+  // compact (r0,r1) pairs into a boundary list usable as blk_row[b], blk_row[b+1]:
+  // blocks are consecutive except across long rows, so store both ends.
+  m->n_stream = (int32_t)(pairs.size() / 2);
+  m->n_segs = (int32_t)segs.size();
+  m->n_long = (int32_t)longs.size();
+
+  const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;
+  auto cleanup = [&](int rc) { sh_csr_free(e, m); return rc; };
+#define HIP_TRY_M(call)                                                         \
+  do {                                                                          \
+    hipError_t _r = (call);                                                     \
+    if (_r != hipSuccess)                                                       \
+      return cleanup(fail(e, _r == hipErrorOutOfMemory ? SH_ENOMEM : SH_EHIP,   \
+                          "%s failed: %s", #call, hipGetErrorString(_r)));      \
+  } while (0)
+  HIP_TRY_M(hipMalloc((void **)&m->d_row_ptr, (rows + 1) * 4));
+  HIP_TRY_M(hipMalloc((void **)&m->d_col, padded * 4));
+  HIP_TRY_M(hipMalloc((void **)&m->d_val, padded * 4));
+  HIP_TRY_M(hipMemsetAsync(m->d_col + (padded - 8 > 0 ? padded - 8 : 0), 0xFF, (padded >= 8 ? 8 : padded) * 4, e->stream));
+  HIP_TRY_M(hipMemsetAsync(m->d_val + (padded - 8 > 0 ? padded - 8 : 0), 0, (padded >= 8 ? 8 : padded) * 4, e->stream));
+  HIP_TRY_M(hipMemcpyAsync(m->d_row_ptr, row_ptr, (rows + 1) * 4, hipMemcpyHostToDevice, e->stream));
+  if (nnz > 0) {
+    HIP_TRY_M(hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMemcpyAsync(m->d_val, val, nnz * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  // The kernel reads blk_row[b] and blk_row[b+1]; with long rows in between the
+  // blocks are not contiguous, so upload the pair list and index it as 2*b.
+  HIP_TRY_M(hipMalloc((void **)&m->d_blk_row, (pairs.size() + 2) * 4));
+  if (!pairs.empty())
+    HIP_TRY_M(hipMemcpyAsync(m->d_blk_row, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, e->stream));
+  if (m->n_segs) {
+    HIP_TRY_M(hipMalloc((void **)&m->d_segs, segs.size() * sizeof(LongSeg)));
+    HIP_TRY_M(hipMemcpyAsync(m->d_segs, segs.data(), segs.size() * sizeof(LongSeg), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_long, longs.size() * sizeof(LongRow)));
+    HIP_TRY_M(hipMemcpyAsync(m->d_long, longs.data(), longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_partial, segs.size() * 4));
+  }
+  HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
+#undef HIP_TRY_M
+  *out = m;
+  return SH_OK;
+}
+
+int sh_csr_free(sh_engine *e, sh_csr *m) {
+  if (!m)
+    return SH_OK;
+  if (e) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+  }
+  if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
+  if (m->d_col) (void)hipFree(m->d_col);
+  if (m->d_val) (void)hipFree(m->d_val);
+  if (m->d_blk_row) (void)hipFree(m->d_blk_row);
+  if (m->d_segs) (void)hipFree(m->d_segs);
+  if (m->d_long) (void)hipFree(m->d_long);
+  if (m->d_partial) (void)hipFree(m->d_partial);
+  delete m;
+  return SH_OK;
+}
+
+int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz) {
+  if (!m)
+    return SH_EINVAL;
+  if (rows) *rows = m->rows;
+  if (cols) *cols = m->cols;
+  if (nnz) *nnz = m->nnz;
+  return SH_OK;
+}
+
+int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes) {
+  if (!m || !bytes)
+    return SH_EINVAL;
+  *bytes = 8ull * m->nnz + 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows +
+           (reads_y ? 4ull * m->rows : 0ull);
+  return SH_OK;
+}
+
+// ---------------------------------------------------------------- vectors
+int sh_vec_alloc(sh_engine *e, int64_t n, sh_vec **out) {
+  if (!e || !out || n < 0)
+    return fail(e, SH_EINVAL, "sh_vec_alloc: bad argument");
+  *out = nullptr;
+  HIP_TRY(e, hipSetDevice(e->device));
+  sh_vec *v = new (std::nothrow) sh_vec();
+  if (!v)
+    return fail(e, SH_ENOMEM, "out of host memory");
+  hipError_t r = hipMalloc(&v->d, (n > 0 ? n : 1) * 4);
+  if (r != hipSuccess) {
+    delete v;
+    return fail(e, SH_ENOMEM, "hipMalloc(%lld B) failed: %s", (long long)n * 4, hipGetErrorString(r));
+  }
+  v->n = n;
+  v->owned = true;
+  *out = v;
+  return SH_OK;
+}
+
+int sh_vec_wrap(sh_engine *e, void *device_ptr, int64_t n, sh_vec **out) {
+  if (!e || !out || n < 0 || (!device_ptr && n > 0))
+    return fail(e, SH_EINVAL, "sh_vec_wrap: bad argument");
+  sh_vec *v = new (std::nothrow) sh_vec();
+  if (!v)
+    return fail(e, SH_ENOMEM, "out of host memory");
+  v->d = device_ptr;
+  v->n = n;
+  v->owned = false;
+  *out = v;
+  return SH_OK;
+}
+
+int sh_vec_free(sh_engine *e, sh_vec *v) {
+  if (!v)
+    return SH_OK;
+  if (v->owned && v->d) {
+    if (e) {
+      (void)hipSetDevice(e->device);
+      (void)hipStreamSynchronize(e->stream);
+    }
+    (void)hipFree(v->d);
+  }
+  delete v;
+  return SH_OK;
+}
+
+int sh_vec_upload(sh_engine *e, sh_vec *v, const void *host, int64_t n) {
+  if (!e || !v || (!host && n > 0) || n < 0)
+    return fail(e, SH_EINVAL, "sh_vec_upload: bad argument");
+  if (n > v->n)
+    return fail(e, SH_ESHAPE, "sh_vec_upload: %lld elements into a vector of %lld", (long long)n, (long long)v->n);
+  HIP_TRY(e, hipMemcpyAsync(v->d, host, n * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return SH_OK;
+}
+
+int sh_vec_download(sh_engine *e, const sh_vec *v, void *host, int64_t n) {
+  if (!e || !v || (!host && n > 0) || n < 0)
+    return fail(e, SH_EINVAL, "sh_vec_download: bad argument");
+  if (n > v->n)
+    return fail(e, SH_ESHAPE, "sh_vec_download: %lld elements from a vector of %lld", (long long)n, (long long)v->n);
+  HIP_TRY(e, hipMemcpyAsync(host, v->d, n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return SH_OK;
+}
+
+int sh_vec_fill(sh_engine *e, sh_vec *v, uint32_t pattern32) {
+  if (!e || !v)
+    return fail(e, SH_EINVAL, "sh_vec_fill: bad argument");
+  if (v->n > 0)
+    HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)v->d, (int)pattern32, v->n, e->stream));
+  return SH_OK;
+}
+
+int sh_vec_copy(sh_engine *e, sh_vec *dst, const sh_vec *src) {
+  if (!e || !dst || !src)
+    return fail(e, SH_EINVAL, "sh_vec_copy: bad argument");
+  if (dst->n != src->n)
+    return fail(e, SH_ESHAPE, "sh_vec_copy: length mismatch");
+  if (src->n > 0)
+    HIP_TRY(e, hipMemcpyAsync(dst->d, src->d, src->n * 4, hipMemcpyDeviceToDevice, e->stream));
+  return SH_OK;
+}
+
+int64_t sh_vec_len(const sh_vec *v) { return v ? v->n : -1; }
+void *sh_vec_device_ptr(const sh_vec *v) { return v ? v->d : nullptr; }
+
+} // extern "C"
+
+// ---------------------------------------------------------------- launches
+template <class SR>
+static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_vec *y,
+                       const void *alpha_p, const void *beta_p, sh_vec *out, StepDev st) {
+  using T = typename SR::T;
+  T alpha, beta;
+  memcpy(&alpha, alpha_p, 4);
+  memcpy(&beta, beta_p, 4);
+  const bool use_y = SR::reads_y(beta);
+  if (use_y && !y)
+    return fail(e, SH_EINVAL, "sh_spmv: y is NULL but the epilogue reads it (beta != 0 or min-plus)");
+  if (use_y && y->n < A->rows)
+    return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
+  CsrDev dev{A->d_row_ptr, A->d_col, A->d_val, (int32_t)A->rows, (int32_t)A->cols};
+  const int grid = A->n_stream + A->n_segs;
+  if (grid > 0) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_csr_kernel<SR>), dim3(grid), dim3(BS), 0, e->stream, dev,
+                       (const uint32_t *)x->d, use_y ? (const uint32_t *)y->d : nullptr, alpha, beta,
+                       use_y ? 1 : 0, (uint32_t *)out->d, A->d_blk_row, A->n_stream, A->d_segs,
+                       A->d_partial, st);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (A->n_long > 0) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_long_fixup<SR>), dim3((A->n_long + 63) / 64), dim3(64), 0,
+                       e->stream, A->d_long, A->n_long, A->d_partial,
+                       use_y ? (const uint32_t *)y->d : nullptr, alpha, beta, use_y ? 1 : 0,
+                       (uint32_t *)out->d, st);
+    HIP_TRY(e, hipGetLastError());
+  }
+  return SH_OK;
+}
+
+static int check_operands(sh_engine *e, const sh_csr *A, const sh_vec *x, const void *alpha,
+                          const void *beta, const sh_vec *out, const char *who) {
+  if (!e || !A || !x || !alpha || !beta || !out)
+    return fail(e, SH_EINVAL, "%s: NULL argument", who);
+  if (x->n < A->cols)
+    return fail(e, SH_ESHAPE, "%s: x has %lld elements, matrix has %lld columns", who, (long long)x->n, (long long)A->cols);
+  if (out->n < A->rows)
+    return fail(e, SH_ESHAPE, "%s: out has %lld elements, matrix has %lld rows", who, (long long)out->n, (long long)A->rows);
+  if (out->d == x->d && A->rows > 0)
+    return fail(e, SH_EINVAL, "%s: out must not alias x", who);
+  return SH_OK;
+}
+
+static int dispatch(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
+                    const void *alpha, const void *beta, sh_vec *out, StepDev st) {
+  switch (sr) {
+  case SH_PLUS_TIMES_F32: return launch_spmv<PlusTimesF32>(e, A, x, y, alpha, beta, out, st);
+  case SH_MIN_PLUS_F32: return launch_spmv<MinPlusF32>(e, A, x, y, alpha, beta, out, st);
+  case SH_OR_AND_I32: return launch_spmv<OrAndI32>(e, A, x, y, alpha, beta, out, st);
+  default: return fail(e, SH_EINVAL, "unknown semiring %d", (int)sr);
+  }
+}
+
+extern "C" {
+
+int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
+            const void *alpha, const void *beta, sh_vec *out, const sh_launch *launch,
+            uint64_t *kernel_ns) {
+  (void)launch; // geometry comes from the matrix schedule (see header)
+  int rc = check_operands(e, A, x, alpha, beta, out, "sh_spmv");
+  if (rc)
+    return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  StepDev st{nullptr, nullptr, 0, 0.0};
+  if (kernel_ns)
+    HIP_TRY(e, hipEventRecord(e->ev0, e->stream));
+  rc = dispatch(e, sr, A, x, y, alpha, beta, out, st);
+  if (rc)
+    return rc;
+  if (kernel_ns) {
+    HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(e, hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *kernel_ns = (uint64_t)((double)ms * 1e6);
+  }
+  return SH_OK;
+}
+
+int sh_spmv_step(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
+                 const void *alpha, const void *beta, sh_vec *out, int64_t x_row_offset, double delta,
+                 int32_t *changed_flag_device) {
+  int rc = check_operands(e, A, x, alpha, beta, out, "sh_spmv_step");
+  if (rc)
+    return rc;
+  if (x_row_offset < 0 || x_row_offset + A->rows > x->n)
+    return fail(e, SH_ESHAPE, "sh_spmv_step: x_row_offset %lld + rows %lld exceeds x length %lld",
+                (long long)x_row_offset, (long long)A->rows, (long long)x->n);
+  HIP_TRY(e, hipSetDevice(e->device));
+  StepDev st{changed_flag_device, (const uint32_t *)x->d, x_row_offset, delta};
+  return dispatch(e, sr, A, x, y, alpha, beta, out, st);
+}
+
+int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const sh_vec *y0,
+               sh_vec *scratch, const void *alpha, const void *beta, double delta, int32_t max_iters,
+               const sh_launch *launch, int32_t *iters, int32_t *converged, uint64_t *ns_per_iter,
+               uint64_t *total_ns) {
+  (void)launch;
+  if (!e || !A || !x || !y0 || !scratch || !alpha || !beta || !iters || !converged || max_iters < 1)
+    return fail(e, SH_EINVAL, "sh_iterate: bad argument");
+  if (A->rows != A->cols)
+    return fail(e, SH_ESHAPE, "sh_iterate: matrix must be square (inc/common.h:49-52)");
+  if (x->n < A->rows || scratch->n < A->rows || y0->n < A->rows)
+    return fail(e, SH_ESHAPE, "sh_iterate: vectors shorter than the matrix");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (e->n_flags < 1) {
+    HIP_TRY(e, hipMalloc((void **)&e->d_flags, 64));
+    e->n_flags = 16;
+  }
+  sh_vec *in = x, *out = scratch;
+  const sh_vec *y = y0;
+  int32_t it = 0;
+  bool term = false;
+  uint64_t total = 0;
+  do {
+    HIP_TRY(e, hipMemsetAsync(e->d_flags, 0, 4, e->stream));
+    StepDev st{e->d_flags, (const uint32_t *)in->d, 0, delta};
+    HIP_TRY(e, hipEventRecord(e->ev0, e->stream));
+    int rc = dispatch(e, sr, A, in, y, alpha, beta, out, st);
+    if (rc)
+      return rc;
+    HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_flag, e->d_flags, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    const uint64_t ns = (uint64_t)((double)ms * 1e6);
+    if (ns_per_iter)
+      ns_per_iter[it] = ns;
+    total += ns;
+    term = (*e->h_flag == 0);
+    sh_vec *t = in; in = out; out = t;   // std::swap(input, output), app/sssp.cpp:143
+    y = in;                              // setGlobalArg(3, input_mem_ptr), :150
+    it++;
+  } while (!term && it < max_iters);
+  if (in != x) {
+    HIP_TRY(e, hipMemcpyAsync(x->d, in->d, A->rows * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  *iters = it;
+  *converged = term ? 1 : 0;
+  if (total_ns)
+    *total_ns = total;
+  return SH_OK;
+}
+
+} // extern "C"

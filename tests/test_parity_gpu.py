@@ -1,0 +1,250 @@
+"""GPU parity: the HIP path, called through the C ABI, against
+  (a) the committed golden vectors produced by the real reference,
+  (b) the pinned CPU oracle on the same seeded inputs,
+  (c) size-independent properties at BASELINE.json's full sizes.
+Integer-valued data (all reference fixtures, all synthetic weights) must match
+bit-for-bit (the reference's own criterion, inc/harness.h:134); general float
+data within 1e-5 relative (north_star); BFS and SSSP vectors and iteration
+counts bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, mtx
+from oracle import oracle as O
+from sparseharness_amd import hostlib as H
+from sparseharness_amd.engine import Engine, EngineError
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5  # north_star tolerance for float SpMV
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def run_spmv(eng, sr, rp, ci, va, x, y, alpha, beta, cols=None):
+    rows = len(rp) - 1
+    cols = len(x) if cols is None else cols
+    dt = O.elem_dtype(sr)
+    A = eng.upload_csr(rows, cols, rp, ci, np.ascontiguousarray(va, dt))
+    xv = eng.vector(np.ascontiguousarray(x, dt))
+    yv = None if y is None else eng.vector(np.ascontiguousarray(y, dt))
+    out = eng.alloc(rows).fill(0)
+    ns = eng.spmv(sr, A, xv, yv, alpha, beta, out, timed=True)
+    res = out.download(dt)
+    for v in (xv, yv, out):
+        if v is not None:
+            v.free()
+    A.free()
+    assert ns > 0
+    return res
+
+
+def assert_close(got, want):
+    tol = REL * np.maximum(1.0, np.abs(want.astype(np.float64)))
+    bad = np.abs(got.astype(np.float64) - want.astype(np.float64)) > tol
+    assert not bad.any(), f"{bad.sum()} elements off, first at {np.argmax(bad)}: {got[np.argmax(bad)]} vs {want[np.argmax(bad)]}"
+
+
+# ------------------------------------------------------------------ (a) golden
+def test_spmv_matches_reference_gold_and_kernel(eng, matrix_name):
+    g = golden(matrix_name)
+    rows, cols, _, rp, ci, va = H.mm_load(mtx(matrix_name))
+    n = rows
+    x1 = np.ones(n, np.float32)
+    xm = (1 + np.arange(n) % 7).astype(np.float32)
+    ym = (np.arange(n) % 5).astype(np.float32)
+    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, x1, None, 1.0, 0.0)
+    np.testing.assert_array_equal(bits(got), bits(g["gold_x1"]))       # Gold<float>::spmv
+    np.testing.assert_array_equal(bits(got), bits(g["kern_spmv_x1"]))  # Lift kernel
+    assert O.check_result(g["gold_x1"], got) == O.CORRECT
+    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, xm, None, 1.0, 0.0)
+    np.testing.assert_array_equal(bits(got), bits(g["gold_xmod"]))
+    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)
+    np.testing.assert_array_equal(bits(got), bits(g["kern_spmv_ab"]))
+
+
+@pytest.mark.parametrize("sr,tag,a,b", [(O.MIN_PLUS_F32, "sssp", 0.0, 0.0), (O.OR_AND_I32, "bfs", 1, 0)])
+def test_iterative_apps_match_reference(eng, matrix_name, sr, tag, a, b):
+    g = golden(matrix_name)
+    dt = O.elem_dtype(sr)
+    rows, cols, _, rp, ci, va = H.mm_load(mtx(matrix_name), elem_is_int=(sr == O.OR_AND_I32))
+    x0 = O.initial_vector(sr, rows)
+    A = eng.upload_csr(rows, cols, rp, ci, va)
+    # one launch
+    xv, yv, out = eng.vector(x0), eng.vector(x0), eng.alloc(rows).fill(0)
+    eng.spmv(sr, A, xv, yv, a, b, out)
+    np.testing.assert_array_equal(bits(out.download(dt)), bits(g[tag + "_first"]))
+    # whole do/while on the device
+    iters, conv, per, total = eng.iterate(sr, A, xv, yv, out, a, b, delta=1e-4, max_iters=2000)
+    assert [iters, int(conv)] == g[tag + "_meta"].tolist()
+    np.testing.assert_array_equal(bits(xv.download(dt)), bits(g[tag + "_final"]))
+    assert len(per) == iters and total == sum(per)
+    for v in (xv, yv, out):
+        v.free()
+    A.free()
+
+
+# ------------------------------------------------------------------ (b) oracle on seeded synthetic inputs
+def synth_cases():
+    rng = np.random.default_rng(1234)
+    cases = {}
+    rp, ci, va = H.powerlaw(200_000, 4_000_000, seed=11)           # long rows + short rows
+    cases["powerlaw_int"] = (rp, ci, va, 200_000)
+    cases["powerlaw_real"] = (rp, ci, (va * rng.uniform(0.5, 1.5, len(va))).astype(np.float32) - 4.0, 200_000)
+    rp, ci, va = H.rmat(15, seed=5)
+    cases["rmat15"] = (rp, ci, va, 1 << 15)
+    # ragged: many empty rows, one very long row, a row of exactly one block, tiny rows
+    deg = np.zeros(5000, np.int64)
+    deg[7] = 70_001; deg[100] = 4096; deg[101] = 4097; deg[200:300] = 1; deg[4999] = 3; deg[1000:1010] = 64
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    ci = rng.integers(0, 5000, rp[-1]).astype(np.int32)
+    va = rng.integers(1, 17, rp[-1]).astype(np.float32)
+    cases["ragged"] = (rp, ci, va, 5000)
+    return cases
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return synth_cases()
+
+
+@pytest.mark.parametrize("name", ["powerlaw_int", "powerlaw_real", "rmat15", "ragged"])
+def test_spmv_matches_oracle(eng, cases, name):
+    rp, ci, va, n = cases[name]
+    xm = (1 + np.arange(n) % 7).astype(np.float32)
+    ym = (np.arange(n) % 5).astype(np.float32)
+    for x, y, a, b in [(np.ones(n, np.float32), None, 1.0, 0.0), (xm, None, 1.0, 0.0), (xm, ym, 2.0, 0.5)]:
+        got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, x, y, a, b)
+        want = O.kernel(O.PLUS_TIMES_F32, rp, ci, va, x, np.zeros(n) if y is None else y, a, b)
+        assert_close(got, want)
+        if name != "powerlaw_real" and np.abs(want).max() < 2 ** 24:
+            np.testing.assert_array_equal(bits(got), bits(want))  # integer-valued: exact
+        if y is None:
+            assert_close(got, O.gold_spmv(rp, ci, va, x))           # and against the gold restatement
+
+
+@pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])
+@pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
+def test_semiring_variants_match_oracle(eng, cases, name, sr):
+    rp, ci, va, n = cases[name]
+    dt = O.elem_dtype(sr)
+    vals = va.astype(dt)
+    x0 = O.initial_vector(sr, n)
+    a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+    got = run_spmv(eng, sr, rp, ci, vals, x0, x0, a, b)
+    np.testing.assert_array_equal(bits(got), bits(O.kernel(sr, rp, ci, vals, x0, x0, a, b)))
+    # general alpha/beta/y
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 3, n).astype(dt)
+    y = rng.integers(0, 50, n).astype(dt)
+    a2, b2 = (2.0, 1.0) if sr == O.MIN_PLUS_F32 else (1, 1)
+    got = run_spmv(eng, sr, rp, ci, vals, x, y, a2, b2)
+    np.testing.assert_array_equal(bits(got), bits(O.kernel(sr, rp, ci, vals, x, y, a2, b2)))
+
+
+@pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
+def test_iterate_matches_oracle_on_rmat(eng, cases, sr):
+    rp, ci, va, n = cases["rmat15"]
+    dt = O.elem_dtype(sr)
+    vals = va.astype(dt)
+    x0 = O.initial_vector(sr, n)
+    a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, delta=1e-4, max_iters=60)
+    A = eng.upload_csr(n, n, rp, ci, vals)
+    xv, yv, sc = eng.vector(x0), eng.vector(x0), eng.alloc(n).fill(0)
+    iters, conv, _, _ = eng.iterate(sr, A, xv, yv, sc, a, b, delta=1e-4, max_iters=60)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
+
+
+def test_edge_cases(eng):
+    # empty matrix rows, nnz == 0, single row, out-of-range / negative columns -> identity
+    rp = np.zeros(11, np.int32)
+    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, np.zeros(0, np.int32), np.zeros(0, np.float32), np.ones(10), np.full(10, 3.0), 1.0, 2.0)
+    assert got.tolist() == [6.0] * 10
+    got = run_spmv(eng, O.MIN_PLUS_F32, rp, np.zeros(0, np.int32), np.zeros(0, np.float32), np.ones(10), np.full(10, 3.0), 0.0, 0.0)
+    assert got.tolist() == [3.0] * 10
+    rp = np.array([0, 3], np.int32)
+    ci = np.array([0, -1, 5], np.int32)
+    va = np.array([1, 10, 100], np.float32)
+    assert run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, [2, 3], None, 1.0, 0.0, cols=2).tolist() == [2.0]
+    assert run_spmv(eng, O.MIN_PLUS_F32, rp, ci, va, [2, 3], [O.FLT_MAX], 0.0, 0.0, cols=2).tolist() == [3.0]
+    assert run_spmv(eng, O.OR_AND_I32, rp, ci, va.astype(np.int32), [0, 1], None, 1, 0, cols=2).tolist() == [0]
+    assert run_spmv(eng, O.OR_AND_I32, rp, np.array([1, -1, 5], np.int32), va.astype(np.int32), [0, 1], None, 1, 0, cols=2).tolist() == [1]
+
+
+def test_error_paths(eng):
+    rp = np.array([0, 1, 2], np.int32)
+    A = eng.upload_csr(2, 2, rp, np.array([0, 1], np.int32), np.ones(2, np.float32))
+    x, out = eng.vector(np.ones(2, np.float32)), eng.alloc(2)
+    with pytest.raises(EngineError) as ei:   # beta != 0 needs y
+        eng.spmv(O.PLUS_TIMES_F32, A, x, None, 1.0, 1.0, out)
+    assert ei.value.code == -1
+    short = eng.alloc(1)
+    with pytest.raises(EngineError) as ei:
+        eng.spmv(O.PLUS_TIMES_F32, A, short, None, 1.0, 0.0, out)
+    assert ei.value.code == -5
+    with pytest.raises(EngineError):
+        eng.spmv(O.PLUS_TIMES_F32, A, x, None, 1.0, 0.0, x)   # out aliases x
+    with pytest.raises(EngineError) as ei:   # inconsistent row_ptr
+        eng.upload_csr(2, 2, np.array([0, 2, 1], np.int32), np.array([0], np.int32), np.ones(1, np.float32))
+    assert ei.value.code == -5
+
+
+def test_step_sets_changed_flag(eng):
+    import ctypes
+    rp, ci, va = H.rmat(10, seed=9)
+    n = 1 << 10
+    A = eng.upload_csr(n, n, rp, ci, va)
+    x0 = O.initial_vector(O.MIN_PLUS_F32, n)
+    x, out, flag = eng.vector(x0), eng.alloc(n), eng.alloc(1).fill(0, np.int32)
+    eng.step(O.MIN_PLUS_F32, A, x, x, 0.0, 0.0, out, 0, 1e-4, flag.device_ptr)
+    assert flag.download(np.int32)[0] == 1
+    final, _, _ = O.iterate(O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)
+    x.upload(final)
+    flag.fill(0, np.int32)
+    eng.step(O.MIN_PLUS_F32, A, x, x, 0.0, 0.0, out, 0, 1e-4, flag.device_ptr)
+    assert flag.download(np.int32)[0] == 0
+    np.testing.assert_array_equal(bits(out.download()), bits(final))
+
+
+# ------------------------------------------------------------------ (c) full-size properties
+@pytest.mark.parametrize("rows,nnz", [(10_000_000, 200_000_000)])
+def test_full_size_powerlaw_properties(eng, rows, nnz):
+    """BASELINE.json config 5 at full size: checksum + linearity + spot rows vs the oracle."""
+    rp, ci, va = H.powerlaw(rows, nnz)
+    A = eng.upload_csr(rows, rows, rp, ci, va)
+    x1 = eng.alloc(rows).fill(1.0)
+    out = eng.alloc(rows)
+    eng.spmv(O.PLUS_TIMES_F32, A, x1, None, 1.0, 0.0, out)
+    y1 = out.download()
+    # checksum of checksums: sum_r y[r] == sum of all weights (x = 1)
+    assert abs(y1.astype(np.float64).sum() - va.astype(np.float64).sum()) <= 1e-6 * va.astype(np.float64).sum()
+    # every row whose exact sum fits in 24 bits must be exact: compare a strided sample + the longest rows to the oracle
+    deg = np.diff(rp)
+    sample = np.unique(np.concatenate([np.arange(0, rows, 9973), np.argsort(deg)[-8:]]))
+    for r in sample:
+        s = va[rp[r]:rp[r + 1]].astype(np.float64).sum()
+        assert abs(float(y1[r]) - s) <= 1e-5 * max(1.0, abs(s)), (r, deg[r])
+        if s < 2 ** 24:
+            assert float(y1[r]) == s
+    # linearity: A(3x) == 3 A(x) exactly for integer data below 2^24
+    x3 = eng.alloc(rows).fill(3.0)
+    out3 = eng.alloc(rows)
+    eng.spmv(O.PLUS_TIMES_F32, A, x3, None, 1.0, 0.0, out3)
+    y3 = out3.download()
+    small = y1 < 2 ** 22
+    np.testing.assert_array_equal(y3[small], 3 * y1[small])
+    # alpha/beta epilogue against the first result
+    eng.spmv(O.PLUS_TIMES_F32, A, x1, out, 2.0, 1.0, out3)
+    np.testing.assert_array_equal(out3.download()[small], 3 * y1[small])

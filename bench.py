@@ -101,7 +101,9 @@ def main():
 
     stream = torch.cuda.current_stream()
     eng = Engine(local_rank, stream=stream.cuda_stream)
+    t_up = time.time()
     A = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va)
+    t_up = time.time() - t_up
     x_host = (1 + np.arange(n) % 7).astype(np.float32)  # a wrong gather cannot pass
     x_t = torch.from_numpy(x_host).cuda()
     out_t = torch.zeros(max(s_rows, 1), dtype=torch.float32, device="cuda")
@@ -154,8 +156,24 @@ def main():
     else:
         want = O.gold_dot(s_rp, s_ci, s_va, x_host, 1.0)
     tol = 1e-5 * np.maximum(1.0, np.abs(want.astype(np.float64)))
-    bad = int((np.abs(y.astype(np.float64) - want.astype(np.float64)) > tol).sum())
+    off = np.nonzero(np.abs(y.astype(np.float64) - want.astype(np.float64)) > tol)[0]
+    # A row whose partial sums pass 2^24 is summed inexactly by the sequential float gold itself
+    # (error ~ n*2^-24); there the GPU's tree order legitimately differs by more than 1e-5.  Such a row
+    # is accepted only if the GPU value is within 1e-5 of the exact (float64) dot AND no farther from it
+    # than the gold is.  Everything else is a mismatch.
+    bad, excused = 0, 0
+    chk_rp, chk_ci, chk_va = (rp, ci, va) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else (s_rp, s_ci, s_va)
+    for r in off:
+        a, b = int(chk_rp[r]), int(chk_rp[r + 1])
+        terms = x_host[chk_ci[a:b]].astype(np.float64) * chk_va[a:b].astype(np.float64)
+        exact = terms.sum()
+        if (np.abs(terms).sum() >= 2 ** 24 and abs(y[r] - exact) <= 1e-5 * max(1.0, abs(exact))
+                and abs(y[r] - exact) <= abs(want[r] - exact)):
+            excused += 1
+        else:
+            bad += 1
     parity = {"checked_rows": int(s_rows), "mismatches_rel_1e-5": bad,
+              "rows_where_gold_itself_is_inexact_and_gpu_is_closer_to_exact": excused,
               "bit_exact_rows": int((y == want).sum())}
 
     alg_bytes = A.algorithmic_bytes(reads_y=False)
@@ -169,12 +187,14 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} nnz-balanced row ranges, x replicated"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": args.traffic_bytes,
-                     "kernel": "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)",
+                     "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2 + spmv_long_fixup <PlusTimesF32>" if A.plan()[0] == "tiled"
+                                else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
                      "rank": rank, "rank_nnz": s_nnz},
         "cpu_baseline": cpu,
         "parity": parity,
-        "gen_seconds": round(t_gen, 2), "device": eng.device_name,
+        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1]},
+        "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,
     }
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -108,6 +108,11 @@ int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
 /* Algorithmic bytes of one SpMV over this matrix:
  * 8*nnz + 4*(rows+1) + 4*cols + 4*rows [+ 4*rows if y is read]. */
 int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
+/* Which execution plan sh_csr_upload chose (SH_PLAN=stream|tiled|auto overrides):
+ * 0 = CSR-stream (x gathered from global memory, for L2-resident x),
+ * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM).
+ * streamed_bytes = HBM bytes one SpMV moves by construction under that plan. */
+int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
 
 /* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /
  *      writeToGlobalArg / fillGlobalArg / readFromGlobalArg

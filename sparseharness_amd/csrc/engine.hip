@@ -10,7 +10,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -42,7 +44,20 @@ struct sh_csr {
   LongRow *d_long = nullptr;
   int32_t n_long = 0;
   uint32_t *d_partial = nullptr;
+  // x-tiled two-phase plan (kernels.hip.h); built when plan == PLAN_TILED
+  int plan = 0;
+  RowBin *d_bins = nullptr;
+  int32_t n_bins = 0;
+  TileChunk *d_chunks = nullptr;
+  int32_t n_chunks = 0;
+  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_P = nullptr;
+  uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
+  LongRow *d_tlong = nullptr;
+  int32_t n_tlong = 0;
+  uint32_t *d_tpartial = nullptr;
+  int64_t stream_len = 0, p_len = 0;
 };
+enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
 
 struct sh_vec {
   void *d = nullptr;
@@ -216,6 +231,139 @@ static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t>
   }
 }
 
+
+// ---- x-tiled two-phase plan (see kernels.hip.h) ---------------------------
+// Host-side layout construction.  CSR order is already (bin, slot) order, so
+// the tile-major stream is a stable partition of the entries by column tile;
+// every (bin, tile) piece is padded to a multiple of 4 entries so that one
+// thread's 16-byte group never straddles pieces and its 4 products land at 4
+// consecutive, 16-byte aligned positions of P.
+struct TiledHost {
+  std::vector<RowBin> bins;
+  std::vector<TileChunk> chunks;
+  std::vector<LongRow> longs;
+  std::vector<uint32_t> tval, gdest;
+  std::vector<uint16_t> tcol, pslot;
+  int64_t stream_len = 0, p_len = 0;
+  int32_t n_partials = 0;
+};
+
+static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
+                             const int32_t *ci, const uint32_t *val, TiledHost &H) {
+  const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) >> TCOLS_LOG2);
+  // 1. row bins
+  for (int64_t r = 0; r < rows;) {
+    const int64_t len = (int64_t)rp[r + 1] - rp[r];
+    if (len > TBIN) {
+      LongRow lr{(int32_t)r, H.n_partials, 0, 0};
+      for (int64_t p = rp[r]; p < rp[r + 1]; p += TBIN) {
+        RowBin b{};
+        b.r0 = (int32_t)r; b.nr = 1; b.csr0 = (int32_t)p;
+        b.cnt = (int32_t)std::min<int64_t>(TBIN, rp[r + 1] - p);
+        b.pslot = H.n_partials++;
+        H.bins.push_back(b);
+        lr.nslots++;
+      }
+      H.longs.push_back(lr);
+      r++;
+      continue;
+    }
+    int64_t r1 = r + 1;
+    while (r1 < rows && r1 - r < TBIN_ROWS && (int64_t)rp[r1 + 1] - rp[r] <= TBIN)
+      r1++;
+    RowBin b{};
+    b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = rp[r]; b.cnt = rp[r1] - rp[r]; b.pslot = -1;
+    H.bins.push_back(b);
+    r = r1;
+  }
+  auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
+  // 2. sweep A: piece sizes -> bin.n, bin.pstart, per-tile stream totals
+  std::vector<int32_t> count(CT, 0);
+  std::vector<int32_t> touched;
+  std::vector<int64_t> tile_total(CT, 0);
+  int64_t p_off = 0;
+  for (auto &b : H.bins) {
+    touched.clear();
+    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
+      const int t = tile_of(ci[j]);
+      if (count[t]++ == 0) touched.push_back(t);
+    }
+    int64_t n = 0;
+    for (int t : touched) {
+      const int32_t padded = (count[t] + 3) & ~3;
+      n += padded;
+      tile_total[t] += padded;
+      count[t] = 0;
+    }
+    b.n = (int32_t)n;
+    if (p_off + n > INT32_MAX) return false;
+    b.pstart = (int32_t)p_off;
+    p_off += n;
+  }
+  H.p_len = p_off;
+  H.stream_len = p_off;
+  if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
+    return false; // padding would cost more than 25 %: keep the stream plan
+  // 3. tile starts
+  std::vector<int64_t> cursor(CT, 0);
+  {
+    int64_t acc = 0;
+    for (int t = 0; t < CT; t++) { cursor[t] = acc; acc += tile_total[t]; }
+  }
+  std::vector<int64_t> tile_start(cursor);
+  H.tval.assign((size_t)H.stream_len, 0u);
+  H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
+  H.gdest.assign((size_t)H.stream_len / 4, 0u);
+  H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
+  // 4. sweep B: fill
+  std::vector<int64_t> piece_stream(CT, 0), piece_p(CT, 0);
+  std::vector<int32_t> fillpos(CT, 0);
+  for (auto &b : H.bins) {
+    touched.clear();
+    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
+      const int t = tile_of(ci[j]);
+      if (count[t]++ == 0) touched.push_back(t);
+    }
+    std::sort(touched.begin(), touched.end());
+    int64_t off = b.pstart;
+    for (int t : touched) {
+      const int32_t padded = (count[t] + 3) & ~3;
+      piece_stream[t] = cursor[t];
+      piece_p[t] = off;
+      for (int32_t q = 0; q < padded; q += 4)
+        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)(off + q);
+      cursor[t] += padded;
+      off += padded;
+      fillpos[t] = 0;
+      count[t] = 0;
+    }
+    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
+      const int32_t c = ci[j];
+      const bool in_range = (uint32_t)c < (uint32_t)cols;
+      const int t = in_range ? (c >> TCOLS_LOG2) : 0;
+      const int32_t k = fillpos[t]++;
+      H.tval[(size_t)(piece_stream[t] + k)] = val[j];
+      H.tcol[(size_t)(piece_stream[t] + k)] = in_range ? (uint16_t)(c & (TCOLS - 1)) : TCOL_IDENTITY;
+      H.pslot[(size_t)(piece_p[t] + k)] = (uint16_t)(j - b.csr0);
+    }
+  }
+  // 5. phase-1 work items
+  for (int t = 0; t < CT; t++)
+    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + tile_total[t]; s0 += TCHUNK) {
+      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + TCHUNK, tile_start[t] + tile_total[t]), 0};
+      H.chunks.push_back(ch);
+    }
+  return true;
+}
+
+static int choose_plan(int64_t cols, int64_t nnz) {
+  const char *e = getenv("SH_PLAN");
+  if (e && !strcmp(e, "stream")) return PLAN_STREAM;
+  if (e && !strcmp(e, "tiled")) return PLAN_TILED;
+  // auto: x beyond the per-XCD L2 (4 MiB) makes global gathers line-miss bound
+  return (cols > (1 << 20) && nnz >= (1 << 22)) ? PLAN_TILED : PLAN_STREAM;
+}
+
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
                   const int32_t *col_idx, const void *val, sh_csr **out) {
   if (!e || !out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_idx || !val)))
@@ -278,6 +426,35 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     HIP_TRY_M(hipMemcpyAsync(m->d_long, longs.data(), longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_partial, segs.size() * 4));
   }
+  TiledHost th;
+  m->plan = PLAN_STREAM;
+  if (choose_plan(cols, nnz) == PLAN_TILED && nnz > 0 &&
+      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, th)) {
+    m->plan = PLAN_TILED;
+    m->n_bins = (int32_t)th.bins.size();
+    m->n_chunks = (int32_t)th.chunks.size();
+    m->n_tlong = (int32_t)th.longs.size();
+    m->stream_len = th.stream_len;
+    m->p_len = th.p_len;
+    HIP_TRY_M(hipMalloc((void **)&m->d_bins, th.bins.size() * sizeof(RowBin)));
+    HIP_TRY_M(hipMemcpyAsync(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_chunks, th.chunks.size() * sizeof(TileChunk)));
+    HIP_TRY_M(hipMemcpyAsync(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_tval, th.tval.size() * 4 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_tval, th.tval.data(), th.tval.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_tcol, th.tcol.size() * 2 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)th.p_len * 4 + 16));
+    if (m->n_tlong) {
+      HIP_TRY_M(hipMalloc((void **)&m->d_tlong, th.longs.size() * sizeof(LongRow)));
+      HIP_TRY_M(hipMemcpyAsync(m->d_tlong, th.longs.data(), th.longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_tpartial, (size_t)th.n_partials * 4));
+    }
+  }
   HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
 #undef HIP_TRY_M
   *out = m;
@@ -298,6 +475,9 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_segs) (void)hipFree(m->d_segs);
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
+  for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
+                  (void *)m->d_pslot, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial})
+    if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
 }
@@ -316,6 +496,20 @@ int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes) {
     return SH_EINVAL;
   *bytes = 8ull * m->nnz + 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows +
            (reads_y ? 4ull * m->rows : 0ull);
+  return SH_OK;
+}
+
+int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
+  if (!m)
+    return SH_EINVAL;
+  if (plan) *plan = m->plan;
+  if (streamed_bytes) {
+    const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
+    *streamed_bytes = (m->plan == PLAN_TILED)
+                          ? 7ull * m->stream_len + 4ull * m->p_len /* phase 1 */ + 6ull * m->p_len /* phase 2 */ +
+                                vec + 128ull * 1024 * m->n_chunks /* x tile per phase-1 workgroup (L2) */
+                          : 8ull * m->nnz + vec;
+  }
   return SH_OK;
 }
 
@@ -422,6 +616,24 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_EINVAL, "sh_spmv: y is NULL but the epilogue reads it (beta != 0 or min-plus)");
   if (use_y && y->n < A->rows)
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
+  if (A->plan == PLAN_TILED) {
+    const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+                       A->d_chunks, A->d_tval, A->d_tcol, A->d_gdest, (const uint32_t *)x->d, (int32_t)A->cols,
+                       A->d_P);
+    HIP_TRY(e, hipGetLastError());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(A->n_bins), dim3(TBS), 0, e->stream, A->d_bins,
+                       A->d_row_ptr, A->d_P, A->d_pslot, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d,
+                       A->d_tpartial, st);
+    HIP_TRY(e, hipGetLastError());
+    if (A->n_tlong > 0) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_long_fixup<SR>), dim3((A->n_tlong + 63) / 64), dim3(64), 0, e->stream,
+                         A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d,
+                         st);
+      HIP_TRY(e, hipGetLastError());
+    }
+    return SH_OK;
+  }
   CsrDev dev{A->d_row_ptr, A->d_col, A->d_val, (int32_t)A->rows, (int32_t)A->cols};
   const int grid = A->n_stream + A->n_segs;
   if (grid > 0) {

@@ -70,6 +70,99 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
   }
 }
 
+
+// Row reduction out of LDS, shared by both plans.  rp[0..nr] are the rows'
+// offsets into prod[].  The number of lanes that cooperate on a row depends
+// only on that row's length, so one long row inside a block of short ones
+// never serialises the workgroup and a row's summation order is the same
+// under every plan:
+//   len <= 24    1 lane, sequential in stored order
+//   len <= 256   8 lanes  (stride-8 partial sums, then xor-tree 4,2,1)
+//   len <= 4096  64 lanes (stride-64 partial sums, then xor-tree 32..1)
+//   longer       the whole workgroup (stride-NT sums, wave trees, then waves in order)
+// Rows are classified by one pass that finishes the short ones on the spot
+// and appends the others to three LDS work lists.
+constexpr int RL_SHORT = 24, RL_MID = 256, RL_WAVE = 4096;
+
+template <int NT, int NNZ_CAP> struct ReduceScratch {
+  uint16_t lst8[NNZ_CAP / (RL_SHORT + 1) + 1];
+  uint16_t lst64[NNZ_CAP / (RL_MID + 1) + 1];
+  uint16_t lstB[NNZ_CAP / (RL_WAVE + 1) + 1];
+  int32_t cnt[4];
+  uint32_t wred[NT / 64];
+};
+
+template <class SR, int NT, int NNZ_CAP>
+__device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t *rp, int nr, int r0,
+                                            ReduceScratch<NT, NNZ_CAP> &sc, const uint32_t *__restrict__ y,
+                                            typename SR::T alpha, typename SR::T beta, bool use_y,
+                                            uint32_t *__restrict__ out, const StepDev &st) {
+  using T = typename SR::T;
+  const int tid = threadIdx.x;
+  // sc.cnt[] was zeroed before the barrier that published prod[]
+  for (int row = tid; row < nr; row += NT) {
+    const int s = rp[row], len = rp[row + 1] - s;
+    if (len <= RL_SHORT) {
+      T acc = SR::identity();
+      for (int j = 0; j < len; j++)
+        acc = SR::add(acc, from_bits<T>(prod[s + j]));
+      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+    } else if (len <= RL_MID) {
+      sc.lst8[atomicAdd(&sc.cnt[0], 1)] = (uint16_t)row;
+    } else if (len <= RL_WAVE) {
+      sc.lst64[atomicAdd(&sc.cnt[1], 1)] = (uint16_t)row;
+    } else {
+      sc.lstB[atomicAdd(&sc.cnt[2], 1)] = (uint16_t)row;
+    }
+  }
+  __syncthreads();
+  const int n8 = sc.cnt[0], n64 = sc.cnt[1], nB = sc.cnt[2];
+  for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
+    const int row = sc.lst8[idx], l = tid & 7;
+    const int e = rp[row + 1];
+    T acc = SR::identity();
+    for (int j = rp[row] + l; j < e; j += 8)
+      acc = SR::add(acc, from_bits<T>(prod[j]));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1)
+      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+    if (l == 0)
+      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+  }
+  for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
+    const int row = sc.lst64[idx], l = tid & 63;
+    const int e = rp[row + 1];
+    T acc = SR::identity();
+    for (int j = rp[row] + l; j < e; j += 64)
+      acc = SR::add(acc, from_bits<T>(prod[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+    if (l == 0)
+      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+  }
+  for (int idx = 0; idx < nB; idx++) {   // nB is workgroup-uniform
+    const int row = sc.lstB[idx];
+    const int e = rp[row + 1];
+    T acc = SR::identity();
+    for (int j = rp[row] + tid; j < e; j += NT)
+      acc = SR::add(acc, from_bits<T>(prod[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+    if ((tid & 63) == 0)
+      sc.wred[tid >> 6] = to_bits<T>(acc);
+    __syncthreads();
+    if (tid == 0) {
+      T t = from_bits<T>(sc.wred[0]);
+      for (int w = 1; w < NT / 64; w++)
+        t = SR::add(t, from_bits<T>(sc.wred[w]));
+      finish_row<SR>(r0 + row, t, y, alpha, beta, use_y, out, st);
+    }
+    __syncthreads();
+  }
+}
+
 template <class SR>
 __global__ __launch_bounds__(BS) void spmv_csr_kernel(
     CsrDev A, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y,
@@ -79,10 +172,13 @@ __global__ __launch_bounds__(BS) void spmv_csr_kernel(
   using T = typename SR::T;
   __shared__ uint32_t prod[NNZ_BLK];
   __shared__ int32_t rp[ROWS_BLK + 1];
-  __shared__ uint32_t wred[BS / 64];
+  __shared__ ReduceScratch<BS, NNZ_BLK> sc;
+  uint32_t *wred = sc.wred;
   const int tid = threadIdx.x;
   const bool use_y = use_y_i != 0;
   const int b = blockIdx.x;
+  if (tid < 4)
+    sc.cnt[tid] = 0;
 
   if (b < n_stream) {
     // ------------------------------------------------------------ stream block
@@ -119,21 +215,11 @@ __global__ __launch_bounds__(BS) void spmv_csr_kernel(
       }
     }
     __syncthreads();
-    // Phase 2: per-row reduction out of LDS with lpr (1..64) lanes per row.
-    int lpr = 1;
-    while (lpr < 64 && nr * lpr * 2 <= BS)
-      lpr <<= 1;
-    const int g = tid / lpr, l = tid & (lpr - 1), ng = BS / lpr;
-    for (int row = g; row < nr; row += ng) {
-      T acc = SR::identity();
-      const int je = rp[row + 1] - base;
-      for (int j = rp[row] - base + l; j < je; j += lpr)
-        acc = SR::add(acc, from_bits<T>(prod[j]));
-      for (int o = lpr >> 1; o > 0; o >>= 1)
-        acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
-      if (l == 0)
-        finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
-    }
+    // Phase 2: per-row reduction out of LDS (rp[] made relative to prod[]).
+    for (int i = tid; i <= nr; i += BS)
+      rp[i] -= base;
+    __syncthreads();
+    reduce_rows_from_lds<SR, BS, NNZ_BLK>(prod, rp, nr, r0, sc, y, alpha, beta, use_y, out, st);
   } else {
     // ------------------------------------------------------- long-row segment
     const LongSeg sg = segs[b - n_stream];
@@ -192,6 +278,159 @@ __global__ __launch_bounds__(64) void spmv_long_fixup(
   for (int k = 0; k < lr.nslots; k++)
     acc = SR::add(acc, from_bits<T>(partial[lr.slot0 + k]));
   finish_row<SR>(lr.row, acc, y, alpha, beta, use_y_i != 0, out, st);
+}
+
+
+// ===========================================================================
+// x-tiled two-phase plan (for matrices whose x does not fit the per-XCD L2).
+//
+// Measured on MI355X (profiles/r01_lab_gather_microbench.log): a random 4-byte
+// gather costs the same whether the 40 MB x sits in Infinity Cache or HBM
+// (~55-60 G gathers/s: every L2 miss moves a whole line) and ~230 G/s when x
+// is L2-resident, while a gather out of LDS runs at the HBM streaming rate of
+// its index stream (~1350 G/s).  So for big x no global gather is issued:
+//
+//   phase 1  (one workgroup per <= TCHUNK entries of one 32768-column tile)
+//     the x tile (128 KiB) is staged in LDS; the tile's entries, stored
+//     tile-major as {val f32, col u16}, are streamed with 16-byte loads,
+//     multiplied against LDS, and each aligned group of 4 products is stored
+//     with one 16-byte store into the product array P at a precomputed
+//     position (gdest, one u32 per 4 entries).
+//   phase 2  (one workgroup per row bin of <= TBIN products)
+//     P is laid out bin-major, so a bin's products are one contiguous stream;
+//     they are scattered into LDS at their CSR slot (u16 per product) and the
+//     rows are reduced out of LDS by the same code as the stream kernel
+//     above (deterministic order, same epilogue).  Rows longer than TBIN are
+//     cut into single-row bins whose partials go through spmv_long_fixup.
+//
+// HBM bytes per entry: 4+2+1 read, 4 written (phase 1), 4+2 read (phase 2)
+// = 17 B vs the 8 B algorithmic, but all of it is streaming.
+// ===========================================================================
+constexpr int TCOLS_LOG2 = 15;
+constexpr int TCOLS = 1 << TCOLS_LOG2;  // columns per x tile (128 KiB of LDS)
+constexpr int TBS = 1024;               // threads per workgroup in both phases
+constexpr int TBIN = 32768;             // products per row bin (128 KiB of LDS)
+constexpr int TBIN_ROWS = 4096;         // rows per bin (row_ptr slice in LDS)
+constexpr int TCHUNK = 131072;          // entries per phase-1 workgroup
+constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 marker: x reads as the identity
+constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
+
+struct TileChunk { int32_t tile, s, e, pad; };              // entries [s,e) of the tile-major stream
+// r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
+// n: products incl. padding at P[pstart .. pstart+n); pslot >= 0: the bin is one piece of a
+// long row and its result goes to partial[pslot].
+struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, pslot, pad; };
+
+template <class SR>
+__global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
+    const TileChunk *__restrict__ chunks, const uint32_t *__restrict__ tval,
+    const uint16_t *__restrict__ tcol, const uint32_t *__restrict__ gdest,
+    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P) {
+  using T = typename SR::T;
+  __shared__ uint32_t xs[TCOLS];
+  const TileChunk ch = chunks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int c0 = ch.tile << TCOLS_LOG2;
+  const uint32_t ident = to_bits<T>(SR::identity());
+  // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
+  for (int i = tid; i < TCOLS; i += TBS)
+    xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
+  __syncthreads();
+  for (int g0 = ch.s / 4 + tid; g0 < ch.e / 4; g0 += TBS * 2) {
+    uint4 v[2];
+    uint2 c[2];
+    uint32_t d[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int g = g0 + k * TBS;
+      if (g < ch.e / 4) {
+        v[k] = reinterpret_cast<const uint4 *>(tval)[g];
+        c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
+        d[k] = gdest[g];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int g = g0 + k * TBS;
+      if (g < ch.e / 4) {
+        const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
+        uint4 p;
+        p.x = to_bits<T>(SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v[k].x)));
+        p.y = to_bits<T>(SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v[k].y)));
+        p.z = to_bits<T>(SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v[k].z)));
+        p.w = to_bits<T>(SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v[k].w)));
+        *reinterpret_cast<uint4 *>(P + d[k]) = p;
+      }
+    }
+  }
+}
+
+template <class SR>
+__global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
+    const RowBin *__restrict__ bins, const int32_t *__restrict__ row_ptr,
+    const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot,
+    const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
+    uint32_t *__restrict__ out, uint32_t *__restrict__ partial, StepDev st) {
+  using T = typename SR::T;
+  __shared__ uint32_t prod[TBIN];
+  __shared__ int32_t rp[TBIN_ROWS + 1];
+  __shared__ ReduceScratch<TBS, TBIN> sc;
+  uint32_t *wred = sc.wred;
+  const RowBin bn = bins[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < 4)
+    sc.cnt[tid] = 0;
+  const bool use_y = use_y_i != 0;
+  const bool segment = bn.pslot >= 0;   // one piece of a long row
+  if (!segment) {
+    for (int i = tid; i <= bn.nr; i += TBS)
+      rp[i] = row_ptr[bn.r0 + i] - bn.csr0;
+  }
+  // products of this bin: one contiguous run of P, scattered to their CSR slot
+  const uint4 *P4 = reinterpret_cast<const uint4 *>(P + bn.pstart);
+  const uint2 *S4 = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
+  const int n4 = bn.n / 4;
+  for (int g0 = tid; g0 < n4; g0 += TBS * 2) {
+    uint4 p[2];
+    uint2 s[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (g0 + k * TBS < n4) {
+        p[k] = P4[g0 + k * TBS];
+        s[k] = S4[g0 + k * TBS];
+      }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (g0 + k * TBS < n4) {
+        const uint32_t sa = s[k].x & 0xFFFFu, sb = s[k].x >> 16, sc = s[k].y & 0xFFFFu, sd = s[k].y >> 16;
+        if (sa != TSLOT_PAD) prod[sa] = p[k].x;
+        if (sb != TSLOT_PAD) prod[sb] = p[k].y;
+        if (sc != TSLOT_PAD) prod[sc] = p[k].z;
+        if (sd != TSLOT_PAD) prod[sd] = p[k].w;
+      }
+  }
+  __syncthreads();
+  if (segment) {
+    // all products belong to one row: block-wide reduction, fixed order
+    const int cnt = bn.cnt;
+    T acc = SR::identity();
+    for (int j = tid; j < cnt; j += TBS)
+      acc = SR::add(acc, from_bits<T>(prod[j]));
+    for (int o = 32; o > 0; o >>= 1)
+      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+    if ((tid & 63) == 0)
+      wred[tid >> 6] = to_bits<T>(acc);
+    __syncthreads();
+    if (tid == 0) {
+      T t = from_bits<T>(wred[0]);
+#pragma unroll
+      for (int w = 1; w < TBS / 64; w++)
+        t = SR::add(t, from_bits<T>(wred[w]));
+      partial[bn.pslot] = to_bits<T>(t);
+    }
+    return;
+  }
+  reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, bn.nr, bn.r0, sc, y, alpha, beta, use_y, out, st);
 }
 
 } // namespace sh

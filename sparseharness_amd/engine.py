@@ -76,6 +76,12 @@ class CsrMatrix:
         self.engine._chk(abi.load().sh_csr_algorithmic_bytes(self.h, int(reads_y), C.byref(b)))
         return b.value
 
+    def plan(self):
+        """('stream'|'tiled', HBM bytes one SpMV streams by construction)."""
+        p, b = C.c_int32(), C.c_uint64()
+        self.engine._chk(abi.load().sh_csr_plan(self.h, C.byref(p), C.byref(b)))
+        return ("stream", "tiled")[p.value], b.value
+
     def free(self):
         if self.h is not None:
             abi.load().sh_csr_free(self.engine.h, self.h)

@@ -27,6 +27,13 @@ def eng():
     e.close()
 
 
+@pytest.fixture(params=["stream", "tiled"], autouse=True)
+def plan(request, monkeypatch):
+    """Every parity test runs under both execution plans of the engine."""
+    monkeypatch.setenv("SH_PLAN", request.param)
+    return request.param
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
@@ -220,10 +227,11 @@ def test_step_sets_changed_flag(eng):
 
 # ------------------------------------------------------------------ (c) full-size properties
 @pytest.mark.parametrize("rows,nnz", [(10_000_000, 200_000_000)])
-def test_full_size_powerlaw_properties(eng, rows, nnz):
+def test_full_size_powerlaw_properties(eng, rows, nnz, plan):
     """BASELINE.json config 5 at full size: checksum + linearity + spot rows vs the oracle."""
     rp, ci, va = H.powerlaw(rows, nnz)
     A = eng.upload_csr(rows, rows, rp, ci, va)
+    assert A.plan()[0] == plan
     x1 = eng.alloc(rows).fill(1.0)
     out = eng.alloc(rows)
     eng.spmv(O.PLUS_TIMES_F32, A, x1, None, 1.0, 0.0, out)

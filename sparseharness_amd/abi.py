@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparseharness_hip.so")
+# SH_LIB lets kernel-tuning runs point at an alternative in-tree build of the same engine
+LIB_PATH = os.environ.get("SH_LIB") or os.path.join(_HERE, "libsparseharness_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SH_OK, SH_EINVAL, SH_ENODEVICE, SH_EHIP, SH_ENOMEM, SH_ESHAPE = 0, -1, -2, -3, -4, -5

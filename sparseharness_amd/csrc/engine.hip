@@ -30,6 +30,7 @@ struct sh_engine {
   int32_t n_flags = 0;
   int32_t *h_flag = nullptr;    // pinned
   char name[256] = {0};
+  int n_cus = 256;
   std::string err;
 };
 
@@ -50,7 +51,8 @@ struct sh_csr {
   int32_t n_bins = 0;
   TileChunk *d_chunks = nullptr;
   int32_t n_chunks = 0;
-  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_P = nullptr;
+  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gsrc = nullptr, *d_P = nullptr;
+  int p_stream_order = 0; // 1: P in tile-major stream order (phase 2 gathers pieces); 0: bin-major
   uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
   LongRow *d_tlong = nullptr;
   int32_t n_tlong = 0;
@@ -137,7 +139,8 @@ static int engine_create(int device, void *stream, bool borrow, sh_engine **out)
     delete e;
     return rc;
   }
-  snprintf(e->name, sizeof e->name, "%s (%s)", prop.name, prop.gcnArchName);
+  snprintf(e->name, sizeof e->name, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName);
+  e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = e;
   return SH_OK;
 }
@@ -242,7 +245,7 @@ struct TiledHost {
   std::vector<RowBin> bins;
   std::vector<TileChunk> chunks;
   std::vector<LongRow> longs;
-  std::vector<uint32_t> tval, gdest;
+  std::vector<uint32_t> tval, gdest, gsrc;
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0;
   int32_t n_partials = 0;
@@ -315,6 +318,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)H.stream_len / 4, 0u);
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
+  H.gsrc.assign((size_t)H.p_len / 4, 0u);
   // 4. sweep B: fill
   std::vector<int64_t> piece_stream(CT, 0), piece_p(CT, 0);
   std::vector<int32_t> fillpos(CT, 0);
@@ -330,8 +334,10 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       const int32_t padded = (count[t] + 3) & ~3;
       piece_stream[t] = cursor[t];
       piece_p[t] = off;
-      for (int32_t q = 0; q < padded; q += 4)
+      for (int32_t q = 0; q < padded; q += 4) {
         H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)(off + q);
+        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(cursor[t] + q);
+      }
       cursor[t] += padded;
       off += padded;
       fillpos[t] = 0;
@@ -446,6 +452,14 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, hipMemcpyHostToDevice, e->stream));
+    {
+      const char *lay = getenv("SH_TILED_LAYOUT");
+      m->p_stream_order = (lay && !strcmp(lay, "binmajor")) ? 0 : 1;
+    }
+    if (m->p_stream_order) {
+      HIP_TRY_M(hipMalloc((void **)&m->d_gsrc, th.gsrc.size() * 4 + 16));
+      HIP_TRY_M(hipMemcpyAsync(m->d_gsrc, th.gsrc.data(), th.gsrc.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
     HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)th.p_len * 4 + 16));
@@ -476,7 +490,7 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
-                  (void *)m->d_pslot, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial})
+                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial})
     if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
@@ -620,11 +634,11 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                        A->d_chunks, A->d_tval, A->d_tcol, A->d_gdest, (const uint32_t *)x->d, (int32_t)A->cols,
-                       A->d_P);
+                       A->d_P, A->p_stream_order);
     HIP_TRY(e, hipGetLastError());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(A->n_bins), dim3(TBS), 0, e->stream, A->d_bins,
-                       A->d_row_ptr, A->d_P, A->d_pslot, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d,
-                       A->d_tpartial, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(TBS), 0,
+                       e->stream, A->d_bins, A->n_bins, A->d_row_ptr, A->d_P, A->d_pslot, A->p_stream_order ? A->d_gsrc : nullptr, yp, alpha, beta,
+                       use_y ? 1 : 0, (uint32_t *)out->d, A->d_tpartial, st);
     HIP_TRY(e, hipGetLastError());
     if (A->n_tlong > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_long_fixup<SR>), dim3((A->n_tlong + 63) / 64), dim3(64), 0, e->stream,

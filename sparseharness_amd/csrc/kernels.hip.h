@@ -49,6 +49,12 @@ struct StepDev {
 struct LongSeg { int32_t row, s, e, slot; };
 struct LongRow { int32_t row, slot0, nslots, pad; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
+// outstanding global load (s_waitcnt vmcnt(0)), which would serialise the register prefetch
+// of the next bin behind the current bin's LDS work; the kernels below exchange data between
+// waves through LDS exclusively, so waiting on lgkmcnt is sufficient.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class SR>
 __device__ inline typename SR::T gather_x(const uint32_t *__restrict__ x, int32_t c, int32_t cols) {
   // bounds ladder of kernel5.json:3: idx < 0 or idx >= VLength -> identity
@@ -115,7 +121,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       sc.lstB[atomicAdd(&sc.cnt[2], 1)] = (uint16_t)row;
     }
   }
-  __syncthreads();
+  lds_barrier();
   const int n8 = sc.cnt[0], n64 = sc.cnt[1], nB = sc.cnt[2];
   for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
     const int row = sc.lst8[idx], l = tid & 7;
@@ -152,14 +158,14 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
     if ((tid & 63) == 0)
       sc.wred[tid >> 6] = to_bits<T>(acc);
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       T t = from_bits<T>(sc.wred[0]);
       for (int w = 1; w < NT / 64; w++)
         t = SR::add(t, from_bits<T>(sc.wred[w]));
       finish_row<SR>(r0 + row, t, y, alpha, beta, use_y, out, st);
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -311,7 +317,14 @@ constexpr int TCOLS = 1 << TCOLS_LOG2;  // columns per x tile (128 KiB of LDS)
 constexpr int TBS = 1024;               // threads per workgroup in both phases
 constexpr int TBIN = 32768;             // products per row bin (128 KiB of LDS)
 constexpr int TBIN_ROWS = 4096;         // rows per bin (row_ptr slice in LDS)
-constexpr int TCHUNK = 131072;          // entries per phase-1 workgroup
+#ifndef SH_TCHUNK
+#define SH_TCHUNK 65536
+#endif
+#ifndef SH_P1_UNROLL
+#define SH_P1_UNROLL 2
+#endif
+constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
+constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
 constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 marker: x reads as the identity
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
 
@@ -325,7 +338,7 @@ template <class SR>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const uint32_t *__restrict__ tval,
     const uint16_t *__restrict__ tcol, const uint32_t *__restrict__ gdest,
-    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P) {
+    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P, int p_in_stream_order) {
   using T = typename SR::T;
   __shared__ uint32_t xs[TCOLS];
   const TileChunk ch = chunks[blockIdx.x];
@@ -333,24 +346,27 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   const int c0 = ch.tile << TCOLS_LOG2;
   const uint32_t ident = to_bits<T>(SR::identity());
   // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
-  for (int i = tid; i < TCOLS; i += TBS)
-    xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
+  if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    for (int i = tid; i < TCOLS / 4; i += TBS)   // full tile, 16-byte aligned: 1 KiB per wave-instruction
+      reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(x + c0)[i];
+  } else {
+    for (int i = tid; i < TCOLS; i += TBS)
+      xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
+  }
   __syncthreads();
-  for (int g0 = ch.s / 4 + tid; g0 < ch.e / 4; g0 += TBS * 2) {
-    uint4 v[2];
-    uint2 c[2];
-    uint32_t d[2];
+  for (int g0 = ch.s / 4 + tid; g0 < ch.e / 4; g0 += TBS * P1U) {
+    uint4 v[P1U];
+    uint2 c[P1U];
+    uint32_t d[P1U];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int g = g0 + k * TBS;
-      if (g < ch.e / 4) {
-        v[k] = reinterpret_cast<const uint4 *>(tval)[g];
-        c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
-        d[k] = gdest[g];
-      }
+    for (int k = 0; k < P1U; k++) {   // unconditional loads on clamped indices: one basic block
+      const int g = min(g0 + k * TBS, ch.e / 4 - 1);
+      v[k] = reinterpret_cast<const uint4 *>(tval)[g];
+      c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
+      d[k] = p_in_stream_order ? (uint32_t)g * 4u : gdest[g];
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < P1U; k++) {
       const int g = g0 + k * TBS;
       if (g < ch.e / 4) {
         const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
@@ -365,72 +381,128 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   }
 }
 
+// Phase 2 is persistent: each workgroup walks bins b = blockIdx.x, += gridDim.x and keeps the
+// NEXT bin's products (and their slots) in registers while it reduces the current one out of
+// LDS, so the HBM stream of bin b+1 overlaps the LDS work of bin b (one workgroup per CU: the
+// 128 KiB product image leaves no room for a second one to do that job).
+constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers TBS*P2U*4 = 32768 products)
+
 template <class SR>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
-    const RowBin *__restrict__ bins, const int32_t *__restrict__ row_ptr,
-    const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot,
+    const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
+    const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
     const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
     uint32_t *__restrict__ out, uint32_t *__restrict__ partial, StepDev st) {
   using T = typename SR::T;
   __shared__ uint32_t prod[TBIN];
   __shared__ int32_t rp[TBIN_ROWS + 1];
   __shared__ ReduceScratch<TBS, TBIN> sc;
-  uint32_t *wred = sc.wred;
-  const RowBin bn = bins[blockIdx.x];
   const int tid = threadIdx.x;
-  if (tid < 4)
-    sc.cnt[tid] = 0;
   const bool use_y = use_y_i != 0;
-  const bool segment = bn.pslot >= 0;   // one piece of a long row
-  if (!segment) {
-    for (int i = tid; i <= bn.nr; i += TBS)
-      rp[i] = row_ptr[bn.r0 + i] - bn.csr0;
-  }
-  // products of this bin: one contiguous run of P, scattered to their CSR slot
-  const uint4 *P4 = reinterpret_cast<const uint4 *>(P + bn.pstart);
-  const uint2 *S4 = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
-  const int n4 = bn.n / 4;
-  for (int g0 = tid; g0 < n4; g0 += TBS * 2) {
-    uint4 p[2];
-    uint2 s[2];
+  const uint4 *P4 = reinterpret_cast<const uint4 *>(P);
+
+  uint4 p[P2U];
+  uint2 s[P2U];
+  constexpr int RPU = TBIN_ROWS / TBS + 1;   // row_ptr entries a thread prefetches
+  int32_t rpn[RPU];
+  // All prefetch loads are issued unconditionally on clamped indices so that they sit in one
+  // basic block and fly together (a per-load `if` makes hipcc wait after each one); the
+  // predicate is applied when the registers are consumed.
+  auto fetch = [&](const RowBin &bn) {
+    if (bn.pslot < 0) {
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-      if (g0 + k * TBS < n4) {
-        p[k] = P4[g0 + k * TBS];
-        s[k] = S4[g0 + k * TBS];
-      }
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-      if (g0 + k * TBS < n4) {
-        const uint32_t sa = s[k].x & 0xFFFFu, sb = s[k].x >> 16, sc = s[k].y & 0xFFFFu, sd = s[k].y >> 16;
-        if (sa != TSLOT_PAD) prod[sa] = p[k].x;
-        if (sb != TSLOT_PAD) prod[sb] = p[k].y;
-        if (sc != TSLOT_PAD) prod[sc] = p[k].z;
-        if (sd != TSLOT_PAD) prod[sd] = p[k].w;
-      }
-  }
-  __syncthreads();
-  if (segment) {
-    // all products belong to one row: block-wide reduction, fixed order
-    const int cnt = bn.cnt;
-    T acc = SR::identity();
-    for (int j = tid; j < cnt; j += TBS)
-      acc = SR::add(acc, from_bits<T>(prod[j]));
-    for (int o = 32; o > 0; o >>= 1)
-      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
-    if ((tid & 63) == 0)
-      wred[tid >> 6] = to_bits<T>(acc);
-    __syncthreads();
-    if (tid == 0) {
-      T t = from_bits<T>(wred[0]);
-#pragma unroll
-      for (int w = 1; w < TBS / 64; w++)
-        t = SR::add(t, from_bits<T>(wred[w]));
-      partial[bn.pslot] = to_bits<T>(t);
+      for (int k = 0; k < RPU; k++)
+        rpn[k] = row_ptr[bn.r0 + min(tid + k * TBS, bn.nr)] - bn.csr0;
     }
+    const int n4 = bn.n / 4;
+    if (n4 == 0)
+      return;
+    // bin-major P (gsrc == nullptr): the bin's products are one contiguous run; stream-order P:
+    // gsrc gives, per group of 4, where phase 1 left them (one piece per column tile).
+    const uint2 *S4 = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
+    uint32_t src[P2U];
+    if (gsrc) {
+      const uint32_t *G4 = gsrc + bn.pstart / 4;
+#pragma unroll
+      for (int k = 0; k < P2U; k++)
+        src[k] = G4[min(tid + k * TBS, n4 - 1)];
+#pragma unroll
+      for (int k = 0; k < P2U; k++)
+        src[k] >>= 2;
+    } else {
+#pragma unroll
+      for (int k = 0; k < P2U; k++)
+        src[k] = (uint32_t)(bn.pstart / 4 + min(tid + k * TBS, n4 - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < P2U; k++)
+      s[k] = S4[min(tid + k * TBS, n4 - 1)];
+#pragma unroll
+    for (int k = 0; k < P2U; k++)
+      p[k] = P4[src[k]];
+  };
+  auto put = [&](uint2 sl, uint4 pr) {
+    const uint32_t sa = sl.x & 0xFFFFu, sb = sl.x >> 16, sc_ = sl.y & 0xFFFFu, sd = sl.y >> 16;
+    if (sa != TSLOT_PAD) prod[sa] = pr.x;
+    if (sb != TSLOT_PAD) prod[sb] = pr.y;
+    if (sc_ != TSLOT_PAD) prod[sc_] = pr.z;
+    if (sd != TSLOT_PAD) prod[sd] = pr.w;
+  };
+
+  int b = blockIdx.x;
+  if (b >= n_bins)
     return;
+  RowBin bn = bins[b];
+  fetch(bn);
+  for (; b < n_bins; b += gridDim.x) {
+    const bool segment = bn.pslot >= 0;   // one piece of a long row
+    const int n4 = bn.n / 4;
+    // (the previous iteration ended with a barrier: prod/rp/sc are free)
+    if (tid < 4)
+      sc.cnt[tid] = 0;
+    if (!segment) {
+#pragma unroll
+      for (int k = 0; k < RPU; k++)
+        if (tid + k * TBS <= bn.nr)
+          rp[tid + k * TBS] = rpn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < P2U; k++)
+      if (tid + k * TBS < n4)
+        put(s[k], p[k]);
+    // padding can push a bin a little past TBS*P2U groups: fetch those directly
+    for (int g = tid + P2U * TBS; g < n4; g += TBS) {
+      const uint32_t src = gsrc ? gsrc[bn.pstart / 4 + g] / 4 : (uint32_t)(bn.pstart / 4 + g);
+      put(reinterpret_cast<const uint2 *>(pslot + bn.pstart)[g], P4[src]);
+    }
+    const RowBin cur = bn;
+    if (b + (int)gridDim.x < n_bins) {   // next bin's stream flies during this bin's reduction
+      bn = bins[b + gridDim.x];
+      fetch(bn);
+    }
+    lds_barrier();
+    if (segment) {
+      // all products belong to one row: block-wide reduction, fixed order
+      T acc = SR::identity();
+      for (int j = tid; j < cur.cnt; j += TBS)
+        acc = SR::add(acc, from_bits<T>(prod[j]));
+      for (int o = 32; o > 0; o >>= 1)
+        acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+      if ((tid & 63) == 0)
+        sc.wred[tid >> 6] = to_bits<T>(acc);
+      lds_barrier();
+      if (tid == 0) {
+        T t = from_bits<T>(sc.wred[0]);
+#pragma unroll
+        for (int w = 1; w < TBS / 64; w++)
+          t = SR::add(t, from_bits<T>(sc.wred[w]));
+        partial[cur.pslot] = to_bits<T>(t);
+      }
+    } else {
+      reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
+    }
+    lds_barrier();
   }
-  reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, bn.nr, bn.r0, sc, y, alpha, beta, use_y, out, st);
 }
 
 } // namespace sh

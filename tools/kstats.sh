@@ -1,0 +1,10 @@
+#!/bin/bash
+# tools/kstats.sh <outdir> [bench args] -- rocprofv3 kernel-trace stats of a short bench run, summary to stdout
+out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
+python3 - $out <<'PY'
+import csv, glob, sys
+for r in csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0])):
+    print(f"{r['Name'][:48]:48s} calls {r['Calls']:>4s} avg_us {float(r['AverageNs'])/1e3:10.1f}")
+PY

@@ -1,0 +1,150 @@
+"""Multi-rank path on CPU: world_size-2 (and 3) gloo runs of the sharded iteration driver
+(sparseharness_amd/distributed.py) with the oracle as the local step, checked bit-for-bit
+against the single-process oracle loop.  What is under test is the product's sharding,
+slotted layout, column remap, all-gather and termination logic -- the device kernel is
+covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+from oracle import oracle as O
+from sparseharness_amd import hostlib as H
+from sparseharness_amd import partition
+from sparseharness_amd.distributed import ShardedIteration, ShardPlan
+
+
+class OracleLocalStep:
+    """Test double for HipLocalStep: same contract, computed by the CPU oracle."""
+
+    device = torch.device("cpu")
+
+    def __init__(self, plan, semiring):
+        self.plan, self.semiring = plan, semiring
+
+    def step(self, x_cur, y_slot, x_next, alpha, beta, delta):
+        p, lay = self.plan, self.plan.layout
+        dt = O.elem_dtype(self.semiring)
+        x = x_cur.numpy().view(dt)
+        y = y_slot.numpy().view(dt)[:p.rows]
+        out = O.kernel(self.semiring, p.row_ptr, p.col_idx, p.val.astype(dt), x, y, alpha, beta, vlength=lay.length)
+        off = lay.slot_offset(p.rank)
+        prev = x[off:off + p.rows]
+        if self.semiring == O.OR_AND_I32:
+            changed = bool((prev != out).any())
+        else:
+            changed = bool((~(np.abs(prev - out).astype(np.float64) < delta)).any())
+        xn = x_next.numpy().view(dt)
+        xn[off:off + p.rows] = out
+        x_next.numpy().view(np.int32)[lay.flag_index(p.rank)] = int(changed)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sr, rp, ci, va, a, b = case
+        n = len(rp) - 1
+        plan = ShardPlan(rp, ci, va, rank, world)
+        x0 = O.initial_vector(sr, n)
+        final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, x0, a, b, 1e-4, 500)
+        q.put((rank, final, iters, conv))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_world(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda t: t[0])
+
+
+def cases():
+    out = {}
+    rp, ci, va = H.rmat(11, seed=77)
+    out["rmat11_sssp"] = (O.MIN_PLUS_F32, rp, ci, va, 0.0, 0.0)
+    out["rmat11_bfs"] = (O.OR_AND_I32, rp, ci, va.astype(np.int32), 1, 0)
+    g = golden("matrix")
+    out["1138bus_sssp"] = (O.MIN_PLUS_F32, g["f32_row_ptr"], g["f32_col_idx"], g["f32_val"], 0.0, 0.0)
+    out["1138bus_bfs"] = (O.OR_AND_I32, g["i32_row_ptr"], g["i32_col_idx"], g["i32_val"], 1, 0)
+    return out
+
+
+@pytest.mark.parametrize("name", ["rmat11_sssp", "rmat11_bfs", "1138bus_sssp", "1138bus_bfs"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_iteration_matches_single_process(name, world):
+    if world == 3 and not name.startswith("1138bus"):
+        pytest.skip("3 ranks exercised on one graph only (keeps the CPU suite short)")
+    case = cases()[name]
+    sr, rp, ci, va, a, b = case
+    n = len(rp) - 1
+    x0 = O.initial_vector(sr, n)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, x0, a, b, 1e-4, 500)
+    res = run_world(world, case)
+    for rank, final, iters, conv in res:
+        assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
+        np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
+    if name == "1138bus_sssp":
+        assert w_it == int(golden("matrix")["sssp_meta"][0])  # the real reference's iteration count
+
+
+def test_world1_driver_equals_oracle():
+    sr, rp, ci, va, a, b = cases()["rmat11_sssp"]
+    n = len(rp) - 1
+    plan = ShardPlan(rp, ci, va, 0, 1)
+    x0 = O.initial_vector(sr, n)
+    final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, x0, a, b)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, x0, a, b)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
+
+
+def test_row_bounds_balance_nnz():
+    rp, ci, va = H.powerlaw(100_000, 2_000_000, seed=3)
+    for parts in (1, 2, 4, 8):
+        b = partition.row_bounds(rp, parts)
+        assert b[0] == 0 and b[-1] == 100_000 and (np.diff(b) >= 0).all() and len(b) == parts + 1
+        share = np.diff(rp[b]).astype(np.float64)
+        longest = np.diff(rp).max()
+        assert share.max() <= 2_000_000 / parts + longest  # within one row of perfect balance
+    # degenerate: more parts than rows, empty matrix
+    b = partition.row_bounds(np.array([0, 5], np.int32), 4)
+    assert b.tolist()[0] == 0 and b.tolist()[-1] == 1
+    assert partition.row_bounds(np.zeros(1, np.int32), 2).tolist() == [0, 0, 0]
+
+
+def test_slotted_layout_roundtrip_and_remap():
+    bounds = np.array([0, 5, 5, 130, 200])
+    lay = partition.SlottedLayout(bounds)
+    assert lay.payload == 128 and lay.slot == 192 and lay.length == 4 * 192
+    v = np.arange(200, dtype=np.float32)
+    s = lay.scatter(v, np.float32(-1))
+    np.testing.assert_array_equal(lay.gather(s), v)
+    idx = np.array([0, 4, 5, 129, 130, 199, -1, 200, 10**6])
+    pos = lay.to_slotted_index(idx)
+    assert pos[-3:].tolist() == [-1, -1, -1]          # out of range stays out of range -> identity
+    np.testing.assert_array_equal(s[pos[:6]], v[idx[:6]])
+    assert lay.flags(s.view(np.int32)).tolist() == [0, 0, 0, 0]
+    rp, ci, va = H.rmat(8, seed=1)
+    r0, r1 = 40, 90
+    srp, sci, sva = partition.take_rows(rp, ci, va, r0, r1)
+    assert srp[0] == 0 and srp[-1] == rp[r1] - rp[r0] and len(sci) == srp[-1]

@@ -256,3 +256,22 @@ def test_full_size_powerlaw_properties(eng, rows, nnz, plan):
     # alpha/beta epilogue against the first result
     eng.spmv(O.PLUS_TIMES_F32, A, x1, out, 2.0, 1.0, out3)
     np.testing.assert_array_equal(out3.download()[small], 3 * y1[small])
+
+
+@pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
+def test_sharded_driver_with_hip_local_step(cases, sr):
+    """The multi-GPU iteration driver's device seam (HipLocalStep -> sh_spmv_step on torch memory,
+    slotted vector layout, fused changed flag) on one rank; the N>1 logic is covered under gloo."""
+    import torch
+    from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
+    rp, ci, va, n = cases["rmat15"]
+    dt = O.elem_dtype(sr)
+    vals = va.astype(dt)
+    a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+    x0 = O.initial_vector(sr, n)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 60)
+    torch.cuda.set_device(0)
+    plan = ShardPlan(rp, ci, vals, 0, 1)
+    final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0)).run(x0, x0, a, b, 1e-4, 60)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(bits(final), bits(want))

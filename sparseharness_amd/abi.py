@@ -78,6 +78,16 @@ def load():
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). "
             "sparseharness_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 with the same SONAME as /opt/rocm's.  Whichever is
+    # loaded first serves the whole process, and torch refuses to see any GPU when it ends up on
+    # a runtime it was not built with.  So when this binding is used from Python, let torch (if
+    # installed) load its runtime first; the engine then shares that one instance, which is also
+    # what makes handing torch streams / tensors to the engine valid.  SH_PRELOAD_TORCH=0 skips it.
+    if os.environ.get("SH_PRELOAD_TORCH", "1") != "0":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

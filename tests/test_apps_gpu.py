@@ -1,0 +1,63 @@
+"""The C++ host mirror end to end on the GPU: the three apps (reference CLI, Harness<> /
+IterativeHarness<> subclasses over the C ABI) on the reference's example matrices."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, mtx
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(ROOT, "sparseharness_amd", "host")
+KERNELS = os.path.join(HOST, "kernels")
+
+
+def run_app(app, matrix, kernel, env_extra=None, *extra):
+    cmd = [os.path.join(HOST, "bin", app), "-m", mtx(matrix), "-f", matrix, "-k", os.path.join(KERNELS, kernel),
+           "-r", os.path.join(KERNELS, "runfile.csv"), "-n", "gpubox", "-e", "exp7", "-i", "3", *extra]
+    env = {k: v for k, v in os.environ.items() if k != "SH_QUIET_TIMERS"}
+    env.update(env_extra or {})
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_spmv_app_reports_correct(matrix_name):
+    r = run_app("spmv_harness", matrix_name, "spmv.json")
+    assert r.returncode == 0, r.stderr[-800:]
+    sql = [l for l in r.stdout.splitlines() if l.startswith("INSERT INTO table_name")]
+    assert len(sql) == 1
+    # 3 raw trials checked against the in-harness gold with exact compare + the median row
+    assert sql[0].count('"correct"') == 3 and sql[0].count('"statisticvalue"') == 1 and "badvalues" not in sql[0]
+    assert re.search(r'\(\d+(\.\d+)?(e-?\d+)?, "correct", "csr-stream", 1280, 256, "gpubox", ".*", "%s",0,0,"RAW_RESULT", "exp7"\)'
+                     % matrix_name, sql[0])
+    assert 'PROFILING_DATUM("hipLaunchKernel", "harness"' in r.stdout
+    assert "SH_PERF median_ms=" in r.stdout
+
+
+def test_spmv_app_chunked_config_pads_height():
+    # chunkSize 128 pads the height like the reference (quirk A-6); gold still compares the first H rows
+    r = run_app("spmv_harness", "matrix4", "spmv_chunk128.json")
+    assert r.returncode == 0 and r.stdout.count('"correct"') >= 3
+    assert "v_MHeight_2 = 128" in r.stderr   # 111 + (128 - 111 % 128), quirk A-6
+
+
+@pytest.mark.parametrize("app,kernel,tag", [("sssp_harness", "sssp.json", "sssp"), ("bfs_harness", "bfs.json", "bfs")])
+@pytest.mark.parametrize("host_loop", ["0", "1"])
+def test_iterative_apps_match_reference(matrix_name, app, kernel, tag, host_loop):
+    g = golden(matrix_name)
+    r = run_app(app, matrix_name, kernel, {"SH_HOST_LOOP": host_loop}, "-x", "2000")
+    assert r.returncode == 0, r.stderr[-800:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("SH_RESULT")][0]
+    iters, conv = int(g[tag + "_meta"][0]), int(g[tag + "_meta"][1])
+    assert f"iterations={iters} converged={conv}" in res
+    fin = g[tag + "_final"]
+    if tag == "sssp":
+        reached = int((fin < np.float32(3.4028235e38)).sum())
+        assert f"reached={reached} " in res
+        assert float(res.split("distance_sum=")[1]) == pytest.approx(float(fin[fin < 3e38].astype(np.float64).sum()), rel=1e-6)
+    else:
+        assert res.endswith(f"set={int((fin != 0).sum())}")
+    sql = [l for l in r.stdout.splitlines() if l.startswith("INSERT INTO table_name")]
+    assert len(sql) == 3                                    # one INSERT per trial
+    assert sql[0].count("RAW_RESULT") == iters and "MULTI_ITERATION_SUM" in sql[0] and "MEDIAN_RESULT" in sql[0]

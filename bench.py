@@ -32,6 +32,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+# HBM bytes per SpMV launch measured in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
+# WRITE_SIZE, MI355X_MICROARCH.md "HBM"); PMC cannot be collected inside this process.  Keyed by
+# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_powerlaw.txt
+MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 4106652280}
+
 WORKLOADS = {
     # name: (kind, rows, nnz, description)
     "powerlaw-10M-200M": ("powerlaw", 10_000_000, 200_000_000,
@@ -186,7 +191,11 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "rows": n, "nnz": nnz_total, "semiring": "plus-times f32",
                    "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} nnz-balanced row ranges, x replicated"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": args.traffic_bytes,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": (args.traffic_bytes if args.traffic_bytes is not None else
+                                 (None if (args.rows or args.nnz) else
+                                  MEASURED_TRAFFIC_BYTES.get((args.workload, A.plan()[0], world)))),
+                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_powerlaw.txt",
                      "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2 + spmv_long_fixup <PlusTimesF32>" if A.plan()[0] == "tiled"
                                 else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),

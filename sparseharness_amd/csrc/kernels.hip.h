@@ -318,7 +318,7 @@ constexpr int TBS = 1024;               // threads per workgroup in both phases
 constexpr int TBIN = 32768;             // products per row bin (128 KiB of LDS)
 constexpr int TBIN_ROWS = 4096;         // rows per bin (row_ptr slice in LDS)
 #ifndef SH_TCHUNK
-#define SH_TCHUNK 65536
+#define SH_TCHUNK 32768
 #endif
 #ifndef SH_P1_UNROLL
 #define SH_P1_UNROLL 2

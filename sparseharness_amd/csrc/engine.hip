@@ -54,9 +54,11 @@ struct sh_csr {
   uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gsrc = nullptr, *d_P = nullptr;
   int p_stream_order = 0; // 1: P in tile-major stream order (phase 2 gathers pieces); 0: bin-major
   uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
-  LongRow *d_tlong = nullptr;
+  LongRow *d_tlong = nullptr;   // heavy rows (pre-reduced in phase 1)
   int32_t n_tlong = 0;
   uint32_t *d_tpartial = nullptr;
+  int32_t *d_lrp = nullptr;     // light row offsets, bit 31 = heavy row
+  int64_t light_len = 0;
   int64_t stream_len = 0, p_len = 0;
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
@@ -244,58 +246,73 @@ static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t>
 struct TiledHost {
   std::vector<RowBin> bins;
   std::vector<TileChunk> chunks;
-  std::vector<LongRow> longs;
-  std::vector<uint32_t> tval, gdest, gsrc;
+  std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
+  std::vector<uint32_t> tval, gdest, gsrc, lrp;
   std::vector<uint16_t> tcol, pslot;
-  int64_t stream_len = 0, p_len = 0;
+  int64_t stream_len = 0, p_len = 0, light_len = 0;
   int32_t n_partials = 0;
 };
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) >> TCOLS_LOG2);
-  // 1. row bins
-  for (int64_t r = 0; r < rows;) {
-    const int64_t len = (int64_t)rp[r + 1] - rp[r];
-    if (len > TBIN) {
-      LongRow lr{(int32_t)r, H.n_partials, 0, 0};
-      for (int64_t p = rp[r]; p < rp[r + 1]; p += TBIN) {
-        RowBin b{};
-        b.r0 = (int32_t)r; b.nr = 1; b.csr0 = (int32_t)p;
-        b.cnt = (int32_t)std::min<int64_t>(TBIN, rp[r + 1] - p);
-        b.pslot = H.n_partials++;
-        H.bins.push_back(b);
-        lr.nslots++;
-      }
-      H.longs.push_back(lr);
-      r++;
-      continue;
+  // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
+  // (row, tile) runs are summed inside phase 1 instead of travelling through P.
+  const int64_t heavy_thr = std::min<int64_t>(TBIN, std::max<int64_t>(512, 8ll * CT));
+  auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
+  auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
+
+  // 1. light row offsets (heavy rows have light length 0 and carry bit 31) and row bins
+  H.lrp.assign((size_t)rows + 1, 0u);
+  {
+    uint32_t acc = 0;
+    for (int64_t r = 0; r < rows; r++) {
+      const bool hv = is_heavy(r);
+      H.lrp[(size_t)r] = acc | (hv ? 0x80000000u : 0u);
+      if (!hv) acc += (uint32_t)(rp[r + 1] - rp[r]);
     }
+    H.lrp[(size_t)rows] = acc;
+  }
+  auto light_off = [&](int64_t r) { return (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu); };
+  for (int64_t r = 0; r < rows;) {
     int64_t r1 = r + 1;
-    while (r1 < rows && r1 - r < TBIN_ROWS && (int64_t)rp[r1 + 1] - rp[r] <= TBIN)
+    while (r1 < rows && r1 - r < TBIN_ROWS && light_off(r1 + 1) - light_off(r) <= TBIN)
       r1++;
     RowBin b{};
-    b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = rp[r]; b.cnt = rp[r1] - rp[r]; b.pslot = -1;
+    b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = (int32_t)light_off(r);
+    b.cnt = (int32_t)(light_off(r1) - light_off(r)); b.pslot = -1;
     H.bins.push_back(b);
     r = r1;
   }
-  auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
-  // 2. sweep A: piece sizes -> bin.n, bin.pstart, per-tile stream totals
+
+  // 2. sweep A.  Each tile's stream is [light pieces, bins in order][heavy pieces, rows in order];
+  //    everything is padded to groups of 4.  A1 sizes the light pieces (-> bin.n, bin.pstart,
+  //    light_total[t]); A2 walks the heavy rows: hrel[t] is the running position inside tile t,
+  //    which fixes where the 64-group wave boundaries of phase 1 fall, hence how a heavy
+  //    (row, tile) piece splits into partials.
   std::vector<int32_t> count(CT, 0);
   std::vector<int32_t> touched;
-  std::vector<int64_t> tile_total(CT, 0);
-  int64_t p_off = 0;
-  for (auto &b : H.bins) {
-    touched.clear();
-    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
+  std::vector<int64_t> light_total(CT, 0), hrel(CT, 0);
+  auto parts_of = [](int64_t rel_start, int32_t padded) -> int32_t {   // 64-group blocks spanned
+    const int64_t g0 = rel_start / 4, g1 = (rel_start + padded) / 4 - 1;
+    return (int32_t)(g1 / 64 - g0 / 64 + 1);
+  };
+  auto count_row = [&](int64_t r) {
+    for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
       const int t = tile_of(ci[j]);
       if (count[t]++ == 0) touched.push_back(t);
     }
+  };
+  int64_t p_off = 0;
+  for (auto &b : H.bins) {
+    touched.clear();
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++)
+      if (!is_heavy(r)) count_row(r);
     int64_t n = 0;
     for (int t : touched) {
       const int32_t padded = (count[t] + 3) & ~3;
       n += padded;
-      tile_total[t] += padded;
+      light_total[t] += padded;
       count[t] = 0;
     }
     b.n = (int32_t)n;
@@ -304,30 +321,54 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     p_off += n;
   }
   H.p_len = p_off;
-  H.stream_len = p_off;
+  H.light_len = p_off;
+  for (int t = 0; t < CT; t++) hrel[t] = light_total[t];
+  for (int64_t r = 0; r < rows; r++) {
+    if (!is_heavy(r)) continue;
+    touched.clear();
+    count_row(r);
+    int32_t np = 0;
+    for (int t : touched) {
+      const int32_t padded = (count[t] + 3) & ~3;
+      np += parts_of(hrel[t], padded);
+      hrel[t] += padded;
+      count[t] = 0;
+    }
+    LongRow lr{(int32_t)r, 0, np, 0};
+    H.heavy.push_back(lr);
+  }
+  int64_t total = 0;
+  std::vector<int64_t> tile_start(CT, 0);
+  for (int t = 0; t < CT; t++) { tile_start[t] = total; total += hrel[t]; }   // hrel = light + heavy
+  if (total > INT32_MAX - 8) return false;
+  H.stream_len = total;
   if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
     return false; // padding would cost more than 25 %: keep the stream plan
-  // 3. tile starts
-  std::vector<int64_t> cursor(CT, 0);
   {
     int64_t acc = 0;
-    for (int t = 0; t < CT; t++) { cursor[t] = acc; acc += tile_total[t]; }
+    for (auto &lr : H.heavy) { lr.slot0 = (int32_t)acc; acc += lr.nslots; }
+    if (acc > 0x7FFFFFF0ll) return false;
+    H.n_partials = (int32_t)acc;
   }
-  std::vector<int64_t> tile_start(cursor);
+
+  // 3. sweep B: same walks, now filling the arrays
   H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)H.stream_len / 4, 0u);
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
   H.gsrc.assign((size_t)H.p_len / 4, 0u);
-  // 4. sweep B: fill
-  std::vector<int64_t> piece_stream(CT, 0), piece_p(CT, 0);
+  std::vector<int64_t> cursor(tile_start), piece_stream(CT, 0), piece_p(CT, 0);
   std::vector<int32_t> fillpos(CT, 0);
+  auto put_entry = [&](int64_t pos, int32_t j) {
+    const int32_t c = ci[j];
+    const bool in_range = (uint32_t)c < (uint32_t)cols;
+    H.tval[(size_t)pos] = val[j];
+    H.tcol[(size_t)pos] = in_range ? (uint16_t)(c & (TCOLS - 1)) : TCOL_IDENTITY;
+  };
   for (auto &b : H.bins) {
     touched.clear();
-    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
-      const int t = tile_of(ci[j]);
-      if (count[t]++ == 0) touched.push_back(t);
-    }
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++)
+      if (!is_heavy(r)) count_row(r);
     std::sort(touched.begin(), touched.end());
     int64_t off = b.pstart;
     for (int t : touched) {
@@ -335,7 +376,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       piece_stream[t] = cursor[t];
       piece_p[t] = off;
       for (int32_t q = 0; q < padded; q += 4) {
-        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)(off + q);
+        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)(off + q);      // bin-major P position (debug layout)
         H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(cursor[t] + q);
       }
       cursor[t] += padded;
@@ -343,20 +384,49 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       fillpos[t] = 0;
       count[t] = 0;
     }
-    for (int32_t j = b.csr0; j < b.csr0 + b.cnt; j++) {
-      const int32_t c = ci[j];
-      const bool in_range = (uint32_t)c < (uint32_t)cols;
-      const int t = in_range ? (c >> TCOLS_LOG2) : 0;
-      const int32_t k = fillpos[t]++;
-      H.tval[(size_t)(piece_stream[t] + k)] = val[j];
-      H.tcol[(size_t)(piece_stream[t] + k)] = in_range ? (uint16_t)(c & (TCOLS - 1)) : TCOL_IDENTITY;
-      H.pslot[(size_t)(piece_p[t] + k)] = (uint16_t)(j - b.csr0);
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
+      if (is_heavy(r)) continue;
+      const int64_t slot0 = light_off(r) - b.csr0;
+      for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
+        const int t = tile_of(ci[j]);
+        const int32_t k = fillpos[t]++;
+        put_entry(piece_stream[t] + k, j);
+        H.pslot[(size_t)(piece_p[t] + k)] = (uint16_t)(slot0 + (j - rp[r]));
+      }
     }
   }
-  // 5. phase-1 work items
+  // cursor[t] now sits at the start of tile t's heavy region
+  std::vector<int64_t> heavy_start(cursor);
+  for (const LongRow &lr : H.heavy) {
+    const int64_t r = lr.row;
+    touched.clear();
+    count_row(r);
+    std::sort(touched.begin(), touched.end());
+    int32_t part = lr.slot0;
+    for (int t : touched) {
+      const int32_t padded = (count[t] + 3) & ~3;
+      piece_stream[t] = cursor[t];
+      for (int32_t q = 0; q < padded; q += 4) {
+        const int64_t grel = (cursor[t] - tile_start[t] + q) / 4;   // group index inside the tile
+        if (q > 0 && grel % 64 == 0) part++;                       // next wave of phase 1
+        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)part;     // partial slot of this group
+      }
+      part++;
+      cursor[t] += padded;
+      fillpos[t] = 0;
+      count[t] = 0;
+    }
+    for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
+      const int t = tile_of(ci[j]);
+      put_entry(piece_stream[t] + fillpos[t]++, j);
+    }
+  }
+  // 4. phase-1 work items: fixed TCHUNK cuts from the tile start (a multiple of 64 groups, so
+  //    wave boundaries are the ones assumed above)
   for (int t = 0; t < CT; t++)
-    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + tile_total[t]; s0 += TCHUNK) {
-      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + TCHUNK, tile_start[t] + tile_total[t]), 0};
+    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + hrel[t]; s0 += TCHUNK) {
+      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + TCHUNK, tile_start[t] + hrel[t]),
+                   (int32_t)heavy_start[t]};
       H.chunks.push_back(ch);
     }
   return true;
@@ -439,7 +509,8 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     m->plan = PLAN_TILED;
     m->n_bins = (int32_t)th.bins.size();
     m->n_chunks = (int32_t)th.chunks.size();
-    m->n_tlong = (int32_t)th.longs.size();
+    m->n_tlong = (int32_t)th.heavy.size();
+    m->light_len = th.light_len;
     m->stream_len = th.stream_len;
     m->p_len = th.p_len;
     HIP_TRY_M(hipMalloc((void **)&m->d_bins, th.bins.size() * sizeof(RowBin)));
@@ -462,11 +533,13 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     }
     HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)th.p_len * 4 + 16));
+    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max(th.p_len, th.stream_len) * 4 + 16));
+    HIP_TRY_M(hipMalloc((void **)&m->d_lrp, th.lrp.size() * 4));
+    HIP_TRY_M(hipMemcpyAsync(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, hipMemcpyHostToDevice, e->stream));
     if (m->n_tlong) {
-      HIP_TRY_M(hipMalloc((void **)&m->d_tlong, th.longs.size() * sizeof(LongRow)));
-      HIP_TRY_M(hipMemcpyAsync(m->d_tlong, th.longs.data(), th.longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_tpartial, (size_t)th.n_partials * 4));
+      HIP_TRY_M(hipMalloc((void **)&m->d_tlong, th.heavy.size() * sizeof(LongRow)));
+      HIP_TRY_M(hipMemcpyAsync(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_tpartial, (size_t)th.n_partials * 4 + 16));
     }
   }
   HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
@@ -490,7 +563,7 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
-                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial})
+                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp})
     if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
@@ -520,8 +593,8 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
   if (streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
-                          ? 7ull * m->stream_len + 4ull * m->p_len /* phase 1 */ + 6ull * m->p_len /* phase 2 */ +
-                                vec + 128ull * 1024 * m->n_chunks /* x tile per phase-1 workgroup (L2) */
+                          ? 7ull * m->stream_len + 4ull * m->light_len /* phase 1 */ + 7ull * m->light_len /* phase 2 */ +
+                                vec + 128ull * 1024 * m->n_chunks /* x tile per phase-1 workgroup (mostly L2) */
                           : 8ull * m->nnz + vec;
   }
   return SH_OK;
@@ -634,16 +707,15 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                        A->d_chunks, A->d_tval, A->d_tcol, A->d_gdest, (const uint32_t *)x->d, (int32_t)A->cols,
-                       A->d_P, A->p_stream_order);
+                       A->d_P, A->p_stream_order, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(TBS), 0,
-                       e->stream, A->d_bins, A->n_bins, A->d_row_ptr, A->d_P, A->d_pslot, A->p_stream_order ? A->d_gsrc : nullptr, yp, alpha, beta,
-                       use_y ? 1 : 0, (uint32_t *)out->d, A->d_tpartial, st);
+                       e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, A->d_pslot,
+                       A->p_stream_order ? A->d_gsrc : nullptr, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());
     if (A->n_tlong > 0) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_long_fixup<SR>), dim3((A->n_tlong + 63) / 64), dim3(64), 0, e->stream,
-                         A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d,
-                         st);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,
+                         A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
     return SH_OK;

@@ -89,6 +89,9 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
 // Rows are classified by one pass that finishes the short ones on the spot
 // and appends the others to three LDS work lists.
 constexpr int RL_SHORT = 24, RL_MID = 256, RL_WAVE = 4096;
+// rp[] entries may carry RP_SKIP: the row is produced elsewhere (heavy rows of the tiled plan)
+// and must be neither written nor tested here.  Offsets stay below 2^30.
+constexpr int32_t RP_SKIP = 1 << 30, RP_MASK = RP_SKIP - 1;
 
 template <int NT, int NNZ_CAP> struct ReduceScratch {
   uint16_t lst8[NNZ_CAP / (RL_SHORT + 1) + 1];
@@ -107,7 +110,9 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   const int tid = threadIdx.x;
   // sc.cnt[] was zeroed before the barrier that published prod[]
   for (int row = tid; row < nr; row += NT) {
-    const int s = rp[row], len = rp[row + 1] - s;
+    const int s = rp[row] & RP_MASK, len = (rp[row + 1] & RP_MASK) - s;
+    if (rp[row] & RP_SKIP)
+      continue;
     if (len <= RL_SHORT) {
       T acc = SR::identity();
       for (int j = 0; j < len; j++)
@@ -125,9 +130,9 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   const int n8 = sc.cnt[0], n64 = sc.cnt[1], nB = sc.cnt[2];
   for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
     const int row = sc.lst8[idx], l = tid & 7;
-    const int e = rp[row + 1];
+    const int e = rp[row + 1] & RP_MASK;
     T acc = SR::identity();
-    for (int j = rp[row] + l; j < e; j += 8)
+    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 8)
       acc = SR::add(acc, from_bits<T>(prod[j]));
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1)
@@ -137,9 +142,9 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   }
   for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
     const int row = sc.lst64[idx], l = tid & 63;
-    const int e = rp[row + 1];
+    const int e = rp[row + 1] & RP_MASK;
     T acc = SR::identity();
-    for (int j = rp[row] + l; j < e; j += 64)
+    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 64)
       acc = SR::add(acc, from_bits<T>(prod[j]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -149,9 +154,9 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   }
   for (int idx = 0; idx < nB; idx++) {   // nB is workgroup-uniform
     const int row = sc.lstB[idx];
-    const int e = rp[row + 1];
+    const int e = rp[row + 1] & RP_MASK;
     T acc = SR::identity();
-    for (int j = rp[row] + tid; j < e; j += NT)
+    for (int j = (rp[row] & RP_MASK) + tid; j < e; j += NT)
       acc = SR::add(acc, from_bits<T>(prod[j]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -287,6 +292,38 @@ __global__ __launch_bounds__(64) void spmv_long_fixup(
 }
 
 
+
+// Heavy rows of the tiled plan: phase 1 leaves one partial per (row, tile, wave-part); one
+// 256-thread block per row adds them (stride-256 sums in slot order, wave xor-trees, then the
+// four waves in order) and applies the epilogue.
+constexpr int HFIX_BS = 256;
+template <class SR>
+__global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
+    const LongRow *__restrict__ rows, const uint32_t *__restrict__ partial,
+    const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
+    uint32_t *__restrict__ out, StepDev st) {
+  using T = typename SR::T;
+  __shared__ uint32_t wred[HFIX_BS / 64];
+  const LongRow lr = rows[blockIdx.x];
+  const int tid = threadIdx.x;
+  T acc = SR::identity();
+  for (int k = tid; k < lr.nslots; k += HFIX_BS)
+    acc = SR::add(acc, from_bits<T>(partial[lr.slot0 + k]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
+  if ((tid & 63) == 0)
+    wred[tid >> 6] = to_bits<T>(acc);
+  __syncthreads();
+  if (tid == 0) {
+    T t = from_bits<T>(wred[0]);
+#pragma unroll
+    for (int w = 1; w < HFIX_BS / 64; w++)
+      t = SR::add(t, from_bits<T>(wred[w]));
+    finish_row<SR>(lr.row, t, y, alpha, beta, use_y_i != 0, out, st);
+  }
+}
+
 // ===========================================================================
 // x-tiled two-phase plan (for matrices whose x does not fit the per-XCD L2).
 //
@@ -327,8 +364,11 @@ constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
 constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 marker: x reads as the identity
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
+constexpr uint32_t THEAVY = 0x80000000u;   // gdest flag: group belongs to a heavy row, low bits = partial slot
 
-struct TileChunk { int32_t tile, s, e, pad; };              // entries [s,e) of the tile-major stream
+// entries [s,e) of the tile-major stream; positions >= hs belong to heavy rows (each tile's stream
+// is [light pieces][heavy pieces])
+struct TileChunk { int32_t tile, s, e, hs; };
 // r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
 // n: products incl. padding at P[pstart .. pstart+n); pslot >= 0: the bin is one piece of a
 // long row and its result goes to partial[pslot].
@@ -338,7 +378,8 @@ template <class SR>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const uint32_t *__restrict__ tval,
     const uint16_t *__restrict__ tcol, const uint32_t *__restrict__ gdest,
-    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P, int p_in_stream_order) {
+    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P, int p_in_stream_order,
+    uint32_t *__restrict__ partial) {
   using T = typename SR::T;
   __shared__ uint32_t xs[TCOLS];
   const TileChunk ch = chunks[blockIdx.x];
@@ -354,13 +395,15 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
       xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
   }
   __syncthreads();
-  for (int g0 = ch.s / 4 + tid; g0 < ch.e / 4; g0 += TBS * P1U) {
+  // ---- light entries: products go to P (sequential 16-byte stores in stream-order layout)
+  const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
+  for (int g0 = ch.s / 4 + tid; g0 < le; g0 += TBS * P1U) {
     uint4 v[P1U];
     uint2 c[P1U];
     uint32_t d[P1U];
 #pragma unroll
     for (int k = 0; k < P1U; k++) {   // unconditional loads on clamped indices: one basic block
-      const int g = min(g0 + k * TBS, ch.e / 4 - 1);
+      const int g = min(g0 + k * TBS, le - 1);
       v[k] = reinterpret_cast<const uint4 *>(tval)[g];
       c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
       d[k] = p_in_stream_order ? (uint32_t)g * 4u : gdest[g];
@@ -368,7 +411,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
 #pragma unroll
     for (int k = 0; k < P1U; k++) {
       const int g = g0 + k * TBS;
-      if (g < ch.e / 4) {
+      if (g < le) {
         const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
         uint4 p;
         p.x = to_bits<T>(SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v[k].x)));
@@ -376,6 +419,52 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
         p.z = to_bits<T>(SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v[k].z)));
         p.w = to_bits<T>(SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v[k].w)));
         *reinterpret_cast<uint4 *>(P + d[k]) = p;
+      }
+    }
+  }
+  // ---- heavy entries (rows averaging >= 8 entries per tile): their products never travel
+  // through P.  gdest holds the partial slot of each group; consecutive lanes with the same slot
+  // are one (row, tile, wave-part) piece: segmented inclusive scan over the wave, the last lane
+  // of the piece stores the sum.  Wave boundaries are fixed by the stream position, so the plan
+  // builder knows every piece's split in advance (deterministic, no atomics).
+  const int hb = max(ch.s, min(ch.e, ch.hs)) / 4, he = ch.e / 4;
+  const int lane = tid & 63;
+  // start on the 64-group boundary (relative to the chunk start) the builder assumed
+  for (int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid; g0 < he; g0 += TBS * P1U) {
+    uint4 v[P1U];
+    uint2 c[P1U];
+    uint32_t d[P1U];
+#pragma unroll
+    for (int k = 0; k < P1U; k++) {
+      const int g = max(hb, min(g0 + k * TBS, he - 1));
+      v[k] = reinterpret_cast<const uint4 *>(tval)[g];
+      c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
+      d[k] = gdest[g];
+    }
+#pragma unroll
+    for (int k = 0; k < P1U; k++) {
+      const int g = g0 + k * TBS;
+      const bool valid = g >= hb && g < he;
+      if (__ballot(valid)) {   // wave-uniform
+        T t = SR::identity();
+        if (valid) {
+          const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
+          t = SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v[k].x));
+          t = SR::add(t, SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v[k].y)));
+          t = SR::add(t, SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v[k].z)));
+          t = SR::add(t, SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v[k].w)));
+        }
+        const uint32_t key = valid ? d[k] : (0x80000000u | (uint32_t)lane);   // invalid lanes never merge
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const T up = from_bits<T>(__shfl_up(to_bits<T>(t), o, 64));
+          const uint32_t kk = __shfl_up(key, o, 64);
+          if (lane >= o && kk == key)
+            t = SR::add(t, up);
+        }
+        const uint32_t knext = __shfl_down(key, 1, 64);
+        if (valid && (lane == 63 || knext != key))
+          partial[d[k]] = to_bits<T>(t);
       }
     }
   }
@@ -392,8 +481,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
     const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
     const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
     const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
-    uint32_t *__restrict__ out, uint32_t *__restrict__ partial, StepDev st) {
-  using T = typename SR::T;
+    uint32_t *__restrict__ out, StepDev st) {
+
   __shared__ uint32_t prod[TBIN];
   __shared__ int32_t rp[TBIN_ROWS + 1];
   __shared__ ReduceScratch<TBS, TBIN> sc;
@@ -409,10 +498,10 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
   // basic block and fly together (a per-load `if` makes hipcc wait after each one); the
   // predicate is applied when the registers are consumed.
   auto fetch = [&](const RowBin &bn) {
-    if (bn.pslot < 0) {
 #pragma unroll
-      for (int k = 0; k < RPU; k++)
-        rpn[k] = row_ptr[bn.r0 + min(tid + k * TBS, bn.nr)] - bn.csr0;
+    for (int k = 0; k < RPU; k++) {   // light row offsets; bit 31 = heavy row (skipped here)
+      const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * TBS, bn.nr)];
+      rpn[k] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)bn.csr0) | ((v >> 31) ? RP_SKIP : 0);
     }
     const int n4 = bn.n / 4;
     if (n4 == 0)
@@ -455,17 +544,14 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
   RowBin bn = bins[b];
   fetch(bn);
   for (; b < n_bins; b += gridDim.x) {
-    const bool segment = bn.pslot >= 0;   // one piece of a long row
     const int n4 = bn.n / 4;
     // (the previous iteration ended with a barrier: prod/rp/sc are free)
     if (tid < 4)
       sc.cnt[tid] = 0;
-    if (!segment) {
 #pragma unroll
-      for (int k = 0; k < RPU; k++)
-        if (tid + k * TBS <= bn.nr)
-          rp[tid + k * TBS] = rpn[k];
-    }
+    for (int k = 0; k < RPU; k++)
+      if (tid + k * TBS <= bn.nr)
+        rp[tid + k * TBS] = rpn[k];
 #pragma unroll
     for (int k = 0; k < P2U; k++)
       if (tid + k * TBS < n4)
@@ -481,26 +567,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
       fetch(bn);
     }
     lds_barrier();
-    if (segment) {
-      // all products belong to one row: block-wide reduction, fixed order
-      T acc = SR::identity();
-      for (int j = tid; j < cur.cnt; j += TBS)
-        acc = SR::add(acc, from_bits<T>(prod[j]));
-      for (int o = 32; o > 0; o >>= 1)
-        acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
-      if ((tid & 63) == 0)
-        sc.wred[tid >> 6] = to_bits<T>(acc);
-      lds_barrier();
-      if (tid == 0) {
-        T t = from_bits<T>(sc.wred[0]);
-#pragma unroll
-        for (int w = 1; w < TBS / 64; w++)
-          t = SR::add(t, from_bits<T>(sc.wred[w]));
-        partial[cur.pslot] = to_bits<T>(t);
-      }
-    } else {
-      reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
-    }
+    reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
     lds_barrier();
   }
 }

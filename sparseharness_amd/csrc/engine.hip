@@ -258,7 +258,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) >> TCOLS_LOG2);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
-  const int64_t heavy_thr = std::min<int64_t>(TBIN, std::max<int64_t>(512, 8ll * CT));
+  int64_t per_tile = 8;
+  if (const char *e = getenv("SH_HEAVY_PER_TILE")) per_tile = std::max(1, atoi(e));   // tuning knob
+  const int64_t heavy_thr = std::min<int64_t>(TBIN, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
   auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
 

@@ -174,6 +174,26 @@ def test_iterate_matches_oracle_on_rmat(eng, cases, sr):
     np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
 
 
+def test_rectangular_and_wide_matrices(eng):
+    """rows != cols (the C ABI allows it; only the apps insist on square) and x spanning many tiles."""
+    rng = np.random.default_rng(99)
+    for rows, cols, nnz in [(50_000, 300_000, 1_500_000), (300_000, 40_000, 2_000_000), (20_000, 2_500_000, 3_000_000)]:
+        deg = rng.multinomial(nnz, np.ones(rows) / rows)
+        deg[:3] = [0, 40_000, 1]          # an empty row, a heavy row, a singleton
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        ci = rng.integers(0, cols, rp[-1]).astype(np.int32)
+        va = rng.integers(1, 17, rp[-1]).astype(np.float32)
+        x = (1 + np.arange(cols) % 7).astype(np.float32)
+        y = (np.arange(rows) % 5).astype(np.float32)
+        got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, x, y, 2.0, 0.5, cols=cols)
+        want = O.kernel(O.PLUS_TIMES_F32, rp, ci, va, x, y, 2.0, 0.5, vlength=cols)
+        np.testing.assert_array_equal(bits(got), bits(want))
+        xi = rng.integers(0, 2, cols).astype(np.int32)
+        got = run_spmv(eng, O.OR_AND_I32, rp, ci, va.astype(np.int32), xi, None, 1, 0, cols=cols)
+        want = O.kernel(O.OR_AND_I32, rp, ci, va.astype(np.int32), xi, np.zeros(rows, np.int32), 1, 0, vlength=cols)
+        np.testing.assert_array_equal(got, want)
+
+
 def test_edge_cases(eng):
     # empty matrix rows, nnz == 0, single row, out-of-range / negative columns -> identity
     rp = np.zeros(11, np.int32)

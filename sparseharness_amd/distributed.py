@@ -65,19 +65,24 @@ class HipLocalStep:
         self.A = self.engine.upload_csr(plan.rows, plan.layout.length, plan.row_ptr, plan.col_idx,
                                         np.ascontiguousarray(plan.val, _np_dtype(semiring)))
         self.device = torch.device("cuda", device_index)
+        self._wrapped = {}   # data_ptr -> engine vector handles (the driver ping-pongs two buffers)
+
+    def _vec(self, ptr, n):
+        v = self._wrapped.get((ptr, n))
+        if v is None:
+            v = self._wrapped[(ptr, n)] = self.engine.wrap(ptr, n)
+        return v
 
     def step(self, x_cur, y_slot, x_next, alpha, beta, delta):
         lay, k = self.plan.layout, self.plan.rank
-        e = self.engine
-        esz = 4
         off = lay.slot_offset(k)
-        x = e.wrap(x_cur.data_ptr(), lay.length)
-        y = e.wrap(y_slot.data_ptr(), self.plan.rows)
-        out = e.wrap(x_next.data_ptr() + off * esz, self.plan.rows)
-        flag_ptr = x_next.data_ptr() + lay.flag_index(k) * esz
-        e.step(self.semiring, self.A, x, y, alpha, beta, out, x_row_offset=off, delta=delta, changed_ptr=flag_ptr)
-        for v in (x, y, out):
-            v.free()
+        x = self._vec(x_cur.data_ptr(), lay.length)
+        y = self._vec(y_slot.data_ptr(), self.plan.rows)
+        out = self._vec(x_next.data_ptr() + off * 4, self.plan.rows)
+        flag = self._vec(x_next.data_ptr() + lay.flag_index(k) * 4, lay.FLAG_PAD)
+        flag.fill(0, np.int32)   # clear my changed word (async, same stream)
+        self.engine.step(self.semiring, self.A, x, y, alpha, beta, out, x_row_offset=off, delta=delta,
+                         changed_ptr=flag.device_ptr)
 
 
 class ShardedIteration:
@@ -102,9 +107,19 @@ class ShardedIteration:
         y_first = torch.from_numpy(np.ascontiguousarray(y0[plan.r0:plan.r1])).to(dev)
         off, flag_i = lay.slot_offset(k), lay.flag_index(k)
         flag_idx = torch.tensor([lay.flag_index(j) for j in range(world)], device=dev, dtype=torch.long)
+        flags_dev = torch.zeros(world, dtype=torch.int32, device=dev)
+        flags_host = torch.zeros(world, dtype=torch.int32)
+        if dev.type == "cuda":
+            flags_host = flags_host.pin_memory()
+        clears_own_flag = isinstance(self.local, HipLocalStep)
         iters, converged = 0, False
+        import time
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t_loop = time.perf_counter()
         while iters < max_iters:
-            x_next[flag_i:flag_i + lay.FLAG_PAD] = 0
+            if not clears_own_flag:
+                x_next[flag_i:flag_i + lay.FLAG_PAD] = 0
             y_slot = y_first if iters == 0 else x_cur[off:off + max(plan.rows, 1)]
             self.local.step(x_cur, y_slot, x_next, alpha, beta, delta)
             if world > 1:
@@ -112,11 +127,15 @@ class ShardedIteration:
                 if dev.type == "cpu":
                     mine = mine.clone()   # gloo does not take an input aliasing the output
                 dist.all_gather_into_tensor(x_next, mine)
-            flags = x_next.view(torch.int32)[flag_idx]
+            torch.index_select(x_next.view(torch.int32), 0, flag_idx, out=flags_dev)
+            flags_host.copy_(flags_dev, non_blocking=True)
+            if dev.type == "cuda":
+                torch.cuda.current_stream().synchronize()
             iters += 1
             x_cur, x_next = x_next, x_cur
-            if not bool((flags != 0).any().item()):
+            if not bool(flags_host.any()):
                 converged = True
                 break
+        self.last_loop_seconds = time.perf_counter() - t_loop   # iterations only (setup/readback excluded)
         final = lay.gather(x_cur.cpu().numpy())
         return final, iters, converged

@@ -711,7 +711,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                        A->d_chunks, A->d_tval, A->d_tcol, A->d_gdest, (const uint32_t *)x->d, (int32_t)A->cols,
                        A->d_P, A->p_stream_order, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(TBS), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
                        e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, A->d_pslot,
                        A->p_stream_order ? A->d_gsrc : nullptr, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());

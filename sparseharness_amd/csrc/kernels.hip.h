@@ -351,9 +351,13 @@ __global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
 // ===========================================================================
 constexpr int TCOLS_LOG2 = 15;
 constexpr int TCOLS = 1 << TCOLS_LOG2;  // columns per x tile (128 KiB of LDS)
-constexpr int TBS = 1024;               // threads per workgroup in both phases
-constexpr int TBIN = 32768;             // products per row bin (128 KiB of LDS)
-constexpr int TBIN_ROWS = 4096;         // rows per bin (row_ptr slice in LDS)
+constexpr int TBS = 1024;               // threads per phase-1 workgroup
+#ifndef SH_TBIN
+#define SH_TBIN 32768
+#endif
+constexpr int TBIN = SH_TBIN;           // products per row bin (LDS image: 4 B each)
+constexpr int T2BS = TBIN / 32;         // threads per phase-2 workgroup (P2U = 8 groups of 4 each)
+constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #ifndef SH_TCHUNK
 #define SH_TCHUNK 32768
 #endif
@@ -474,10 +478,10 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
 // NEXT bin's products (and their slots) in registers while it reduces the current one out of
 // LDS, so the HBM stream of bin b+1 overlaps the LDS work of bin b (one workgroup per CU: the
 // 128 KiB product image leaves no room for a second one to do that job).
-constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers TBS*P2U*4 = 32768 products)
+constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers T2BS*P2U*4 = 32768 products)
 
 template <class SR>
-__global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
+__global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
     const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
     const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
     const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
@@ -485,14 +489,14 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
 
   __shared__ uint32_t prod[TBIN];
   __shared__ int32_t rp[TBIN_ROWS + 1];
-  __shared__ ReduceScratch<TBS, TBIN> sc;
+  __shared__ ReduceScratch<T2BS, TBIN> sc;
   const int tid = threadIdx.x;
   const bool use_y = use_y_i != 0;
   const uint4 *P4 = reinterpret_cast<const uint4 *>(P);
 
   uint4 p[P2U];
   uint2 s[P2U];
-  constexpr int RPU = TBIN_ROWS / TBS + 1;   // row_ptr entries a thread prefetches
+  constexpr int RPU = TBIN_ROWS / T2BS + 1;   // row_ptr entries a thread prefetches
   int32_t rpn[RPU];
   // All prefetch loads are issued unconditionally on clamped indices so that they sit in one
   // basic block and fly together (a per-load `if` makes hipcc wait after each one); the
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
   auto fetch = [&](const RowBin &bn) {
 #pragma unroll
     for (int k = 0; k < RPU; k++) {   // light row offsets; bit 31 = heavy row (skipped here)
-      const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * TBS, bn.nr)];
+      const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * T2BS, bn.nr)];
       rpn[k] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)bn.csr0) | ((v >> 31) ? RP_SKIP : 0);
     }
     const int n4 = bn.n / 4;
@@ -514,18 +518,18 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
       const uint32_t *G4 = gsrc + bn.pstart / 4;
 #pragma unroll
       for (int k = 0; k < P2U; k++)
-        src[k] = G4[min(tid + k * TBS, n4 - 1)];
+        src[k] = G4[min(tid + k * T2BS, n4 - 1)];
 #pragma unroll
       for (int k = 0; k < P2U; k++)
         src[k] >>= 2;
     } else {
 #pragma unroll
       for (int k = 0; k < P2U; k++)
-        src[k] = (uint32_t)(bn.pstart / 4 + min(tid + k * TBS, n4 - 1));
+        src[k] = (uint32_t)(bn.pstart / 4 + min(tid + k * T2BS, n4 - 1));
     }
 #pragma unroll
     for (int k = 0; k < P2U; k++)
-      s[k] = S4[min(tid + k * TBS, n4 - 1)];
+      s[k] = S4[min(tid + k * T2BS, n4 - 1)];
 #pragma unroll
     for (int k = 0; k < P2U; k++)
       p[k] = P4[src[k]];
@@ -550,14 +554,14 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
       sc.cnt[tid] = 0;
 #pragma unroll
     for (int k = 0; k < RPU; k++)
-      if (tid + k * TBS <= bn.nr)
-        rp[tid + k * TBS] = rpn[k];
+      if (tid + k * T2BS <= bn.nr)
+        rp[tid + k * T2BS] = rpn[k];
 #pragma unroll
     for (int k = 0; k < P2U; k++)
-      if (tid + k * TBS < n4)
+      if (tid + k * T2BS < n4)
         put(s[k], p[k]);
-    // padding can push a bin a little past TBS*P2U groups: fetch those directly
-    for (int g = tid + P2U * TBS; g < n4; g += TBS) {
+    // padding can push a bin a little past T2BS*P2U groups: fetch those directly
+    for (int g = tid + P2U * T2BS; g < n4; g += T2BS) {
       const uint32_t src = gsrc ? gsrc[bn.pstart / 4 + g] / 4 : (uint32_t)(bn.pstart / 4 + g);
       put(reinterpret_cast<const uint2 *>(pslot + bn.pstart)[g], P4[src]);
     }
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase2(
       fetch(bn);
     }
     lds_barrier();
-    reduce_rows_from_lds<SR, TBS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
+    reduce_rows_from_lds<SR, T2BS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
     lds_barrier();
   }
 }

@@ -99,7 +99,7 @@ def main():
     t_gen = time.time() - t_gen
 
     # ---- shard: nnz-balanced contiguous row ranges
-    bounds = partition.row_bounds(rp, world)
+    bounds = partition.row_bounds(rp, world, cols=n)   # ranges of equal estimated HBM work
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     s_rp, s_ci, s_va = partition.take_rows(rp, ci, va, r0, r1)
     s_rows, s_nnz = r1 - r0, int(s_rp[-1])
@@ -189,7 +189,7 @@ def main():
         "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "rows": n, "nnz": nnz_total, "semiring": "plus-times f32",
-                   "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} nnz-balanced row ranges, x replicated"},
+                   "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} work-balanced contiguous row ranges, x replicated"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": (args.traffic_bytes if args.traffic_bytes is not None else

@@ -254,7 +254,7 @@ struct TiledHost {
 };
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
-                             const int32_t *ci, const uint32_t *val, TiledHost &H) {
+                             const int32_t *ci, const uint32_t *val, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) >> TCOLS_LOG2);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
@@ -276,9 +276,18 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     H.lrp[(size_t)rows] = acc;
   }
   auto light_off = [&](int64_t r) { return (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu); };
+  // Bins are filled up to TBIN products.  (Sizing them so that every CU gets the same number of
+  // bins was tried for shard-sized matrices: the smaller (bin, tile) pieces cost more than the
+  // ragged last round saves -- 0.115 vs 0.105 ms on a 1/8 shard.  SH_BALANCED_BINS=1 re-enables it.)
+  int64_t bin_target = TBIN;
+  if (getenv("SH_BALANCED_BINS") && getenv("SH_BALANCED_BINS")[0] == '1') {
+    const int64_t total_light = light_off(rows);
+    const int64_t rounds = std::max<int64_t>(1, (total_light + (int64_t)TBIN * n_cus - 1) / ((int64_t)TBIN * n_cus));
+    bin_target = std::min<int64_t>(TBIN, std::max<int64_t>(4096, (total_light + rounds * n_cus - 1) / (rounds * n_cus)));
+  }
   for (int64_t r = 0; r < rows;) {
     int64_t r1 = r + 1;
-    while (r1 < rows && r1 - r < TBIN_ROWS && light_off(r1 + 1) - light_off(r) <= TBIN)
+    while (r1 < rows && r1 - r < TBIN_ROWS && light_off(r1 + 1) - light_off(r) <= bin_target)
       r1++;
     RowBin b{};
     b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = (int32_t)light_off(r);
@@ -423,14 +432,29 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       put_entry(piece_stream[t] + fillpos[t]++, j);
     }
   }
-  // 4. phase-1 work items: fixed TCHUNK cuts from the tile start (a multiple of 64 groups, so
-  //    wave boundaries are the ones assumed above)
+  // 4. phase-1 work items.  Cuts are multiples of 64 groups from the tile start (so wave
+  //    boundaries are the ones assumed above).  Order: workgroups are dealt round-robin over
+  //    the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a
+  //    chunk of a tile with tile % 8 == p % 8: every XCD then stages only its own eighth of x
+  //    through its L2 instead of all of it (speed only; correctness does not depend on placement).
+  int64_t chunk = TCHUNK;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
+  if (const char *e = getenv("SH_CHUNK")) chunk = std::max(1024, atoi(e)) & ~255;   // tuning knob
+  const bool xcd_order = !(getenv("SH_XCD_ORDER") && getenv("SH_XCD_ORDER")[0] == '0');
+  std::vector<TileChunk> per_xcd[8];
   for (int t = 0; t < CT; t++)
-    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + hrel[t]; s0 += TCHUNK) {
-      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + TCHUNK, tile_start[t] + hrel[t]),
+    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + hrel[t]; s0 += chunk) {
+      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + chunk, tile_start[t] + hrel[t]),
                    (int32_t)heavy_start[t]};
-      H.chunks.push_back(ch);
+      per_xcd[xcd_order ? (t & 7) : 0].push_back(ch);
     }
+  size_t longest = 0;
+  for (auto &v : per_xcd) longest = std::max(longest, v.size());
+  if (!xcd_order)
+    H.chunks = per_xcd[0];
+  else
+    for (size_t i = 0; i < longest; i++)
+      for (int c = 0; c < 8; c++)
+        H.chunks.push_back(i < per_xcd[c].size() ? per_xcd[c][i] : TileChunk{0, 0, 0, 0});   // empty filler
   return true;
 }
 
@@ -507,7 +531,7 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
   TiledHost th;
   m->plan = PLAN_STREAM;
   if (choose_plan(cols, nnz) == PLAN_TILED && nnz > 0 &&
-      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, th)) {
+      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, e->n_cus, th)) {
     m->plan = PLAN_TILED;
     m->n_bins = (int32_t)th.bins.size();
     m->n_chunks = (int32_t)th.chunks.size();

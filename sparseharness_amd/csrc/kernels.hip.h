@@ -387,6 +387,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   using T = typename SR::T;
   __shared__ uint32_t xs[TCOLS];
   const TileChunk ch = chunks[blockIdx.x];
+  if (ch.s >= ch.e)
+    return;   // filler that keeps the XCD-aligned chunk order
   const int tid = threadIdx.x;
   const int c0 = ch.tile << TCOLS_LOG2;
   const uint32_t ident = to_bits<T>(SR::identity());

@@ -43,7 +43,7 @@ class ShardPlan:
     def __init__(self, row_ptr, col_idx, val, rank, world):
         self.rank, self.world = rank, world
         self.rows_total = len(row_ptr) - 1
-        self.bounds = partition.row_bounds(row_ptr, world)
+        self.bounds = partition.row_bounds(row_ptr, world, cols=self.rows_total)
         self.layout = partition.SlottedLayout(self.bounds)
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
         rp, ci, va = partition.take_rows(row_ptr, col_idx, val, self.r0, self.r1)

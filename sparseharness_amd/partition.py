@@ -16,13 +16,26 @@ on the host, from global row ids to slotted positions.
 import numpy as np
 
 
-def row_bounds(row_ptr, parts):
-    """Boundaries b[0..parts] of contiguous row ranges with ~nnz/parts entries each."""
+def row_bounds(row_ptr, parts, cols=None):
+    """Boundaries b[0..parts] of contiguous row ranges of ~equal WORK.
+
+    Without `cols`: equal stored entries per range.  With `cols` (the x length) and a matrix big
+    enough for the engine's x-tiled plan, entries are weighted by the HBM bytes that plan moves
+    for them: ~18 B for an entry of a light row, ~7 B for an entry of a heavy row (rows averaging
+    >= 8 entries per 32768-column tile, pre-reduced inside phase 1).  A shard
+    full of heavy rows would otherwise finish early while the others still stream."""
     row_ptr = np.asarray(row_ptr)
     rows = len(row_ptr) - 1
-    nnz = int(row_ptr[-1])
-    targets = (np.arange(1, parts, dtype=np.float64) * nnz / parts)
-    cuts = np.searchsorted(row_ptr, targets, side="left").astype(np.int64)
+    if cols is not None and cols > (1 << 20) and int(row_ptr[-1]) >= (1 << 22):
+        deg = np.diff(row_ptr).astype(np.int64)
+        thr = max(512, 8 * ((int(cols) + 32767) // 32768))
+        work = np.where(deg >= thr, 7 * deg, 18 * deg)
+        cum = np.concatenate([[0], np.cumsum(work)])
+    else:
+        cum = row_ptr.astype(np.int64)
+    total = int(cum[-1])
+    targets = (np.arange(1, parts, dtype=np.float64) * total / parts)
+    cuts = np.searchsorted(cum, targets, side="left").astype(np.int64)
     b = np.concatenate([[0], np.clip(cuts, 0, rows), [rows]])
     return np.maximum.accumulate(b)
 

@@ -279,7 +279,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // Bins are filled up to TBIN products.  (Sizing them so that every CU gets the same number of
   // bins was tried for shard-sized matrices: the smaller (bin, tile) pieces cost more than the
   // ragged last round saves -- 0.115 vs 0.105 ms on a 1/8 shard.  SH_BALANCED_BINS=1 re-enables it.)
-  int64_t bin_target = TBIN;
+  // every (bin, tile) piece is padded to 4: leave room so that a padded bin never exceeds TBIN
+  // (phase 2 prefetches exactly TBIN products per bin into registers)
+  int64_t bin_target = std::max<int64_t>(TBIN / 2, (int64_t)TBIN - 3ll * CT);
   if (getenv("SH_BALANCED_BINS") && getenv("SH_BALANCED_BINS")[0] == '1') {
     const int64_t total_light = light_off(rows);
     const int64_t rounds = std::max<int64_t>(1, (total_light + (int64_t)TBIN * n_cus - 1) / ((int64_t)TBIN * n_cus));

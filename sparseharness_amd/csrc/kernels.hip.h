@@ -551,26 +551,56 @@ __global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
   fetch(bn);
   for (; b < n_bins; b += gridDim.x) {
     const int n4 = bn.n / 4;
+    const RowBin cur = bn;
+    const bool has_next = b + (int)gridDim.x < n_bins;
+    if (has_next)
+      bn = bins[b + gridDim.x];
     // (the previous iteration ended with a barrier: prod/rp/sc are free)
     if (tid < 4)
       sc.cnt[tid] = 0;
 #pragma unroll
     for (int k = 0; k < RPU; k++)
-      if (tid + k * T2BS <= bn.nr)
+      if (tid + k * T2BS <= cur.nr)
         rp[tid + k * T2BS] = rpn[k];
+    // Scatter the current bin out of the registers and refill each register pair with the NEXT
+    // bin's group as soon as it is free: the next bin's whole stream is in flight before this
+    // bin's reduction starts.  (gsrc of the next bin is fetched first: P addresses depend on it.)
+    const int nn4 = has_next ? bn.n / 4 : 0;
+    const uint2 *S4n = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
+    uint32_t srcn[P2U];
+    if (nn4 > 0) {
+      if (gsrc) {
+        const uint32_t *G4 = gsrc + bn.pstart / 4;
 #pragma unroll
-    for (int k = 0; k < P2U; k++)
+        for (int k = 0; k < P2U; k++)
+          srcn[k] = G4[min(tid + k * T2BS, nn4 - 1)];
+      } else {
+#pragma unroll
+        for (int k = 0; k < P2U; k++)
+          srcn[k] = (uint32_t)(bn.pstart + 4 * min(tid + k * T2BS, nn4 - 1));
+      }
+    }
+    if (has_next) {
+#pragma unroll
+      for (int k = 0; k < RPU; k++) {
+        const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * T2BS, bn.nr)];
+        rpn[k] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)bn.csr0) | ((v >> 31) ? RP_SKIP : 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < P2U; k++) {
       if (tid + k * T2BS < n4)
         put(s[k], p[k]);
-    // padding can push a bin a little past T2BS*P2U groups: fetch those directly
-    for (int g = tid + P2U * T2BS; g < n4; g += T2BS) {
-      const uint32_t src = gsrc ? gsrc[bn.pstart / 4 + g] / 4 : (uint32_t)(bn.pstart / 4 + g);
-      put(reinterpret_cast<const uint2 *>(pslot + bn.pstart)[g], P4[src]);
+      if (nn4 > 0) {   // workgroup-uniform
+        s[k] = S4n[min(tid + k * T2BS, nn4 - 1)];
+        p[k] = P4[srcn[k] >> 2];
+      }
     }
-    const RowBin cur = bn;
-    if (b + (int)gridDim.x < n_bins) {   // next bin's stream flies during this bin's reduction
-      bn = bins[b + gridDim.x];
-      fetch(bn);
+    // bins are sized so that padding never pushes them past T2BS*P2U groups (engine.hip); this
+    // loop only runs for plans built with other limits
+    for (int g = tid + P2U * T2BS; g < n4; g += T2BS) {
+      const uint32_t src = gsrc ? gsrc[cur.pstart / 4 + g] / 4 : (uint32_t)(cur.pstart / 4 + g);
+      put(reinterpret_cast<const uint2 *>(pslot + cur.pstart)[g], P4[src]);
     }
     lds_barrier();
     reduce_rows_from_lds<SR, T2BS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);

@@ -12,6 +12,9 @@
 #include <iostream>
 
 #include "sh_host.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace {
 
@@ -54,25 +57,85 @@ Banner parse_banner(const std::string &line) {
   return b;
 }
 
+// Token scanner over the in-memory file.  Integers and the common decimal forms are converted
+// by hand (no libc call, no locale: strtod does not scale across threads here); the decimal
+// fast path is Clinger's exact case -- at most 15 significant digits and |exponent| <= 22, so
+// the mantissa and the power of ten are both exact doubles and one multiply or divide gives the
+// correctly rounded result, i.e. bit-for-bit what strtod / the reference's fscanf("%lg") return.
+// Everything else (long mantissas, huge exponents, inf/nan, hex floats) falls back to strtod.
 struct Scanner {
   const char *p, *end;
-  void skip_ws() { while (p < end && std::isspace((unsigned char)*p)) ++p; }
+  static bool ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+  void skip_ws() { while (p < end && ws(*p)) ++p; }
   bool next_int(int &v) {
     skip_ws();
     if (p >= end) return false;
-    char *q;
-    long t = std::strtol(p, &q, 10);
-    if (q == p) return false;
-    p = q; v = (int)t;
+    const char *q = p;
+    bool neg = false;
+    if (*q == '-' || *q == '+') { neg = *q == '-'; ++q; }
+    if (q >= end || *q < '0' || *q > '9') return false;
+    long long acc = 0;
+    int digits = 0;
+    while (q < end && *q >= '0' && *q <= '9') {
+      if (++digits > 18) { char *e; long t = std::strtol(p, &e, 10); p = e; v = (int)t; return true; }
+      acc = acc * 10 + (*q++ - '0');
+    }
+    p = q;
+    v = (int)(neg ? -acc : acc);
     return true;
   }
   bool next_double(double &v) {
     skip_ws();
     if (p >= end) return false;
-    char *q;
-    v = std::strtod(p, &q);
-    if (q == p) return false;
-    p = q;
+    static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *q = p;
+    bool neg = false;
+    if (*q == '-' || *q == '+') { neg = *q == '-'; ++q; }
+    unsigned long long mant = 0;
+    int sig = 0, frac = 0;
+    bool any = false, lead = true;
+    while (q < end && *q >= '0' && *q <= '9') {
+      any = true;
+      if (!(lead && *q == '0')) { lead = false; if (++sig <= 19) mant = mant * 10 + (unsigned)(*q - '0'); }
+      ++q;
+    }
+    if (q < end && *q == '.') {
+      ++q;
+      while (q < end && *q >= '0' && *q <= '9') {
+        any = true;
+        if (!(lead && *q == '0')) { lead = false; if (++sig <= 19) mant = mant * 10 + (unsigned)(*q - '0'); }
+        ++frac;
+        ++q;
+      }
+    }
+    int ex = 0;
+    bool fast = any && sig <= 15;
+    if (fast && q < end && (*q == 'e' || *q == 'E')) {
+      const char *r = q + 1;
+      bool eneg = false;
+      if (r < end && (*r == '-' || *r == '+')) { eneg = *r == '-'; ++r; }
+      if (r < end && *r >= '0' && *r <= '9') {
+        int edig = 0;
+        while (r < end && *r >= '0' && *r <= '9') { if (++edig > 4) { fast = false; break; } ex = ex * 10 + (*r++ - '0'); }
+        if (eneg) ex = -ex;
+        q = r;
+      }
+    }
+    // a following letter (hex float, "inf", "nan", 'd' exponents ...) is strtod's business
+    if (fast && q < end && ((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z'))) fast = false;
+    const int e10 = ex - frac;
+    if (fast && e10 >= -22 && e10 <= 22) {
+      double d = (double)mant;   // exact: < 10^15 < 2^53
+      d = e10 >= 0 ? d * p10[e10] : d / p10[-e10];
+      v = neg ? -d : d;
+      p = q;
+      return true;
+    }
+    char *e;
+    v = std::strtod(p, &e);
+    if (e == p) return false;
+    p = e;
     return true;
   }
   std::string next_line() {
@@ -162,18 +225,93 @@ template <typename T> void SparseMatrix<T>::load_from_file(const std::string &fi
   std::vector<T> ev;
   const std::size_t cap = (std::size_t)nonz * (b.symmetric ? 2 : 1);
   ei.reserve(cap); ej.reserve(cap); ev.reserve(cap);
-  for (int k = 0; k < nonz; k++) {
-    int I = 0, J = 0;
-    double v = 1.0;
-    sc.next_int(I);
-    sc.next_int(J);
-    if (!b.pattern)
-      sc.next_double(v);
+  auto emit = [&](int I, int J, double v) {
     --I; --J;
     const T tv = narrow<T>(v, trunc);
     ei.push_back(I); ej.push_back(J); ev.push_back(tv);
     if (b.symmetric && I != J) {
       ei.push_back(J); ej.push_back(I); ev.push_back(tv);
+    }
+  };
+  // Fast path: the body is cut at line boundaries into one slice per thread and
+  // tokenised in parallel, then stitched together in file order.  It assumes what every
+  // MatrixMarket writer produces -- one entry per line -- and is only kept when it finds
+  // exactly `nonz` entries; otherwise the sequential token scanner below, which like the
+  // reference's fscanf loop (src/sparse_matrix.cpp:49-63) does not care about line structure,
+  // redoes the job.
+  bool parsed = false;
+  const std::size_t body = (std::size_t)(sc.end - sc.p);
+  if (nonz >= 50000 && body > (1u << 20)) {
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = std::max(1, omp_get_max_threads());
+#endif
+    nthreads = (int)std::min<std::size_t>((std::size_t)nthreads, body / (256u << 10) + 1);
+    std::vector<const char *> cut((std::size_t)nthreads + 1);
+    cut[0] = sc.p;
+    cut[(std::size_t)nthreads] = sc.end;
+    for (int t = 1; t < nthreads; t++) {
+      const char *q = sc.p + body * (std::size_t)t / (std::size_t)nthreads;
+      while (q < sc.end && *q != '\n') ++q;
+      cut[(std::size_t)t] = q < sc.end ? q + 1 : sc.end;
+    }
+    // one cache-line-aligned slot per thread: the vectors' end pointers and `out` are written for
+    // every entry, and unaligned neighbours made the threads fight over cache lines
+    struct alignas(128) Part { std::vector<int32_t> I, J; std::vector<T> V; std::size_t out = 0; bool ok = true; };
+    std::vector<Part> parts((std::size_t)nthreads);
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int t = 0; t < nthreads; t++) {
+      Part &pt = parts[(std::size_t)t];
+      Scanner ls{cut[(std::size_t)t], cut[(std::size_t)t + 1]};
+      std::size_t lines = 0;
+      for (const char *q = ls.p; q < ls.end; ++q)
+        lines += *q == '\n';
+      pt.I.reserve(lines + 1); pt.J.reserve(lines + 1); pt.V.reserve(lines + 1);
+      for (;;) {
+        ls.skip_ws();
+        if (ls.p >= ls.end) break;
+        int I = 0, J = 0;
+        double v = 1.0;
+        if (!ls.next_int(I) || !ls.next_int(J) || (!b.pattern && !ls.next_double(v))) { pt.ok = false; break; }
+        // the rest of the line must be blank: anything else means tokens are not one entry per line
+        while (ls.p < ls.end && *ls.p != '\n') {
+          if (!Scanner::ws(*ls.p)) { pt.ok = false; break; }
+          ++ls.p;
+        }
+        if (!pt.ok) break;
+        pt.I.push_back(I - 1); pt.J.push_back(J - 1); pt.V.push_back(narrow<T>(v, trunc));
+        pt.out += (b.symmetric && I != J) ? 2 : 1;
+      }
+    }
+    std::size_t total = 0, total_out = 0;
+    bool ok = true;
+    for (auto &pt : parts) { ok = ok && pt.ok; total += pt.I.size(); total_out += pt.out; }
+    if (ok && total == (std::size_t)nonz) {
+      ei.resize(total_out); ej.resize(total_out); ev.resize(total_out);
+      std::vector<std::size_t> base((std::size_t)nthreads + 1, 0);
+      for (int t = 0; t < nthreads; t++) base[(std::size_t)t + 1] = base[(std::size_t)t] + parts[(std::size_t)t].out;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+      for (int t = 0; t < nthreads; t++) {
+        const Part &pt = parts[(std::size_t)t];
+        std::size_t o = base[(std::size_t)t];
+        for (std::size_t k = 0; k < pt.I.size(); k++) {
+          ei[o] = pt.I[k]; ej[o] = pt.J[k]; ev[o] = pt.V[k]; o++;
+          if (b.symmetric && pt.I[k] != pt.J[k]) { ei[o] = pt.J[k]; ej[o] = pt.I[k]; ev[o] = pt.V[k]; o++; }
+        }
+      }
+      parsed = true;
+    }
+    LOG_DEBUG("parallel MatrixMarket parse on ", nthreads, " threads: ", parsed ? "ok" : "fell back to the sequential scanner");
+  }
+  if (!parsed) {
+    for (int k = 0; k < nonz; k++) {
+      int I = 0, J = 0;
+      double v = 1.0;
+      sc.next_int(I);
+      sc.next_int(J);
+      if (!b.pattern)
+        sc.next_double(v);
+      emit(I, J, v);
     }
   }
   // counting sort by row (= file column J), stable => file order inside a row

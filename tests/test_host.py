@@ -112,3 +112,76 @@ def test_host_gold_equals_oracle_gold_on_synthetic():
     ref = np.add.reduceat((x[ci].astype(np.float64) * va), rp[:-1].clip(max=len(ci) - 1))
     ref[np.diff(rp) == 0] = 0
     np.testing.assert_allclose(y, ref, rtol=1e-6)
+
+
+def _write_mtx(path, header, n, entries):
+    with open(path, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate {header}\n% generated by the test\n{n} {n} {len(entries)}\n")
+        f.write("\n".join(entries) + "\n")
+
+
+def test_number_formats_match_fscanf_semantics(tmp_path):
+    """The hand-rolled tokenizer (exact decimal fast path + strtod fallback) must agree bit-for-bit
+    with the oracle's fscanf("%d %d %lg") restatement on every spelling a .mtx may contain."""
+    vals = ["1474.779", "-9.017", "+3.5", ".5", "5.", "1e3", "1E-3", "-2.5e+2", "123456789012345678901234567890",
+            "0.1234567890123456789", "1e22", "1e23", "9007199254740993", "4.9e-324", "1.7976931348623157e308",
+            "0", "-0.0", "007", "3.0000000000000001e5", "2147483647.9", "16", "1e-22", "12345.6789e-2"]
+    entries = [f"{i + 1} {(i * 7) % len(vals) + 1} {v}" for i, v in enumerate(vals)]
+    p = tmp_path / "formats.mtx"
+    _write_mtx(p, "real general", len(vals), entries)
+    for trunc in (True, False):
+        got = H.mm_load(str(p), truncate=trunc)
+        if trunc:
+            want = O.mm_load(str(p))
+            assert got[:3] == want[:3]
+            for a, b in zip(got[3:], want[3:]):
+                np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                              b.view(np.uint32) if b.dtype == np.float32 else b)
+        else:   # untruncated values == numpy's correctly rounded float32(float64(text))
+            with np.errstate(over="ignore"):
+                ref = {(i, (i * 7) % len(vals)): np.float32(np.float64(v)) for i, v in enumerate(vals)}
+            rows, cols, _, rp, ci, va = got
+            for r in range(rows):
+                for j in range(rp[r], rp[r + 1]):
+                    assert va[j].view(np.uint32) == ref[(ci[j], r)].view(np.uint32), (ci[j], r)
+
+
+@pytest.mark.parametrize("header,sym", [("real general", False), ("integer symmetric", True), ("pattern symmetric", True)])
+def test_parallel_parse_path_matches_oracle(tmp_path, header, sym):
+    """> 1 MiB body and >= 50 000 entries takes the sliced (OpenMP) tokenizer."""
+    rng = np.random.default_rng(8)
+    n, m = 60_000, 120_000
+    I, J = rng.integers(1, n + 1, m), rng.integers(1, n + 1, m)
+    if "pattern" in header:
+        entries = [f"{a} {b}" for a, b in zip(I, J)]
+    elif "integer" in header:
+        entries = [f"{a} {b} {c}" for a, b, c in zip(I, J, rng.integers(-99, 100, m))]
+    else:
+        entries = [f"{a}   {b}\t{c:.9f} " for a, b, c in zip(I, J, rng.uniform(-1e4, 1e4, m))]
+    p = tmp_path / "big.mtx"
+    _write_mtx(p, header, n, entries)
+    assert os.path.getsize(p) > (1 << 20)
+    for as_int in (False, True):
+        got, want = H.mm_load(str(p), elem_is_int=as_int), O.mm_load(str(p), elem_is_int=as_int)
+        assert got[:3] == want[:3]
+        for a, b in zip(got[3:], want[3:]):
+            np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_entries_not_one_per_line_fall_back_to_token_scanner(tmp_path):
+    # the reference's fscanf loop ignores line structure; so must the loader
+    rng = np.random.default_rng(9)
+    n, m = 50_000, 60_000
+    toks = []
+    for a, b, c in zip(rng.integers(1, n + 1, m), rng.integers(1, n + 1, m), rng.integers(1, 99, m)):
+        toks += [str(a), str(b), f"{c}.25"]
+    p = tmp_path / "wrapped.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate real general\n{n} {n} {m}\n")
+        for k in range(0, len(toks), 7):          # 7 tokens per line: entries straddle lines
+            f.write(" ".join(toks[k:k + 7]) + "          \n")
+        f.write("\n" * 20000 + " " * (1 << 20) + "\n")   # make the body > 1 MiB
+    got, want = H.mm_load(str(p)), O.mm_load(str(p))
+    assert got[:3] == want[:3]
+    for a, b in zip(got[3:], want[3:]):
+        np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))

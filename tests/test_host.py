@@ -185,3 +185,12 @@ def test_entries_not_one_per_line_fall_back_to_token_scanner(tmp_path):
     assert got[:3] == want[:3]
     for a, b in zip(got[3:], want[3:]):
         np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_cpp_host_mirror_selftest(tmp_path):
+    """Run / CSV / size-expression evaluator / SqlStat text / KernelConfig JSON / loader + encode + gold,
+    checked in C++ against the behaviour the reference documents (host/test/host_selftest.cpp)."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "selftest"], stderr=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HOST, "bin", "host_selftest"), str(tmp_path)], capture_output=True, text=True,
+                       env={**os.environ, "SH_QUIET_TIMERS": "1"})
+    assert r.returncode == 0 and "all passed" in r.stdout, r.stdout[-800:]

@@ -295,3 +295,19 @@ def test_sharded_driver_with_hip_local_step(cases, sr):
     final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0)).run(x0, x0, a, b, 1e-4, 60)
     assert (iters, conv) == (w_it, w_conv)
     np.testing.assert_array_equal(bits(final), bits(want))
+
+
+def test_iteration_cap_on_a_graph_that_never_settles(eng):
+    """(or,and) BFS with beta = 0 on a 2-cycle oscillates for ever (the reference would spin: TODO.md:7-8);
+    the engine stops at max_iters with converged = false and the same vector as the oracle."""
+    rp = np.array([0, 1, 2, 2], np.int32)          # row0 <- col1, row1 <- col0, row2 empty
+    ci = np.array([1, 0], np.int32)
+    va = np.array([1, 1], np.int32)
+    x0 = np.array([1, 0, 0], np.int32)
+    want, w_it, w_conv = O.iterate(O.OR_AND_I32, rp, ci, va, x0, x0, 1, 0, 1e-4, 7)
+    assert (w_it, w_conv) == (7, False)
+    A = eng.upload_csr(3, 3, rp, ci, va)
+    x, y, sc = eng.vector(x0), eng.vector(x0), eng.alloc(3)
+    iters, conv, per, _ = eng.iterate(O.OR_AND_I32, A, x, y, sc, 1, 0, 1e-4, 7)
+    assert (iters, conv, len(per)) == (7, False, 7)
+    np.testing.assert_array_equal(x.download(np.int32), want)

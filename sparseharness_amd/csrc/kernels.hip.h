@@ -353,7 +353,7 @@ constexpr int TCOLS_LOG2 = 15;
 constexpr int TCOLS = 1 << TCOLS_LOG2;  // columns per x tile (128 KiB of LDS)
 constexpr int TBS = 1024;               // threads per phase-1 workgroup
 #ifndef SH_TBIN
-#define SH_TBIN 32768
+#define SH_TBIN 16384   // 32768: one 1024-thread WG per CU; 16384: two 512-thread WGs (measured 5 % faster)
 #endif
 constexpr int TBIN = SH_TBIN;           // products per row bin (LDS image: 4 B each)
 constexpr int T2BS = TBIN / 32;         // threads per phase-2 workgroup (P2U = 8 groups of 4 each)
@@ -478,8 +478,9 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
 
 // Phase 2 is persistent: each workgroup walks bins b = blockIdx.x, += gridDim.x and keeps the
 // NEXT bin's products (and their slots) in registers while it reduces the current one out of
-// LDS, so the HBM stream of bin b+1 overlaps the LDS work of bin b (one workgroup per CU: the
-// 128 KiB product image leaves no room for a second one to do that job).
+// LDS, so the HBM stream of bin b+1 overlaps the LDS work of bin b.  With 16384-product bins two
+// such workgroups share a CU (2 x 64 KiB images), which also keeps HBM requests in flight while
+// one of them sits between its barriers.
 constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers T2BS*P2U*4 = 32768 products)
 
 template <class SR>

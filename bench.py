@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 # HBM bytes per SpMV launch measured in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
 # WRITE_SIZE, MI355X_MICROARCH.md "HBM"); PMC cannot be collected inside this process.  Keyed by
 # (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_final_powerlaw.txt
-MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 3335394792}
+MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 3051375624}
 
 WORKLOADS = {
     # name: (kind, rows, nnz, description)

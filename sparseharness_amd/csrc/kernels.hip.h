@@ -545,7 +545,16 @@ __global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
     if (sd != TSLOT_PAD) prod[sd] = pr.w;
   };
 
-  int b = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (blocks w and w+8 share one).  Neighbouring
+  // bins own neighbouring pieces of every tile in P, so the 128-B lines at piece boundaries are
+  // wanted by both: give consecutive bins to workgroups of the SAME XCD so that the shared line
+  // is fetched into one L2 once instead of into two (speed only; any placement is correct).
+  const int G = gridDim.x;
+#ifdef SH_NO_XCD_BINS
+  int b = (int)blockIdx.x;
+#else
+  int b = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+#endif
   if (b >= n_bins)
     return;
   RowBin bn = bins[b];

@@ -21,7 +21,7 @@
  *     and all its work is ordered on it (the reference has one in-order
  *     queue, inc/harness.h:79-80);
  *   - all vector/matrix elements are 4 bytes: float for SH_PLUS_TIMES_F32 and
- *     SH_MIN_PLUS_F32, int32 for SH_OR_AND_I32;
+ *     SH_MIN_PLUS_F32, int32 for SH_OR_AND_I32 and SH_MAX_MIN_I32;
  *   - there is NO CPU fallback: without a HIP device sh_engine_create fails
  *     with SH_ENODEVICE.
  */
@@ -51,11 +51,15 @@ enum {
  *   MIN_PLUS:   mult |a|+|b|, add min(|a|,|b|), identity FLT_MAX,
  *               out = min(|dot|+|alpha|, |y|+|beta|)
  *   OR_AND:     mult (a!=0)&&(b!=0), add ||, identity 0,
- *               out = (dot&&alpha) || (y&&beta)                         */
+ *               out = (dot&&alpha) || (y&&beta)
+ *   MAX_MIN:    (example/scc/kernel5.json:3) mult min, add max, identity INT_MIN,
+ *               out = max(min(dot,alpha), min(y,beta))
+ * PageRank (example/pr/kernel5.json:3) is PLUS_TIMES with beta = (1-d)/N.      */
 typedef enum {
   SH_PLUS_TIMES_F32 = 0,
   SH_MIN_PLUS_F32 = 1,
-  SH_OR_AND_I32 = 2
+  SH_OR_AND_I32 = 2,
+  SH_MAX_MIN_I32 = 3
 } sh_semiring;
 
 /* Launch geometry handed down from the run-file: replaces class Run
@@ -133,7 +137,8 @@ void *sh_vec_device_ptr(const sh_vec *v);
  *      running a Lift kernel (example/<algo>/kernel*.json:3):
  *        out[r] = epilogue( (+)_j ( x[col_j] (x) val_j ), alpha, y[r], beta )
  *      alpha/beta point to one element of the semiring's type.  y may be NULL
- *      when the epilogue does not read it (PLUS_TIMES or OR_AND with beta==0).
+ *      when the epilogue does not read it (PLUS_TIMES or OR_AND with beta==0,
+ *      MAX_MIN with beta==INT_MIN).
  *      out must not alias x.  If kernel_ns != NULL the call waits and returns
  *      the device time of the launch(es) in ns (hipEvent START->STOP, as the
  *      reference's CL_PROFILING_COMMAND_START/END, inc/harness.h:183-194);

@@ -12,7 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsh_oracle.so")
 
-PLUS_TIMES_F32, MIN_PLUS_F32, OR_AND_I32 = 0, 1, 2
+PLUS_TIMES_F32, MIN_PLUS_F32, OR_AND_I32, MAX_MIN_I32 = 0, 1, 2, 3
+NORM_NONE, NORM_PAGERANK, NORM_SCC = 0, 1, 2
+INT_MIN, INT_MAX = -2**31, 2**31 - 1
 FLT_MAX = np.float32(3.4028235e38)
 CORRECT, NOT_CHECKED, BAD_LENGTH, BAD_VALUES = 0, 1, 3, 4
 
@@ -32,6 +34,7 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_mm_load.restype = C.c_int
+        _lib.oracle_mm_load_ex.restype = C.c_int
         _lib.oracle_kernel.restype = C.c_int
         _lib.oracle_iterate.restype = C.c_int
         _lib.oracle_check_result_f32.restype = C.c_int
@@ -46,17 +49,18 @@ def _p(a):
 
 
 def elem_dtype(semiring):
-    return np.int32 if semiring == OR_AND_I32 else np.float32
+    return np.int32 if semiring in (OR_AND_I32, MAX_MIN_I32) else np.float32
 
 
-def mm_load(path, elem_is_int=False):
-    """MatrixMarket -> (rows, cols, hdr_nnz, row_ptr, col_idx, val) with the reference's quirks."""
+def mm_load(path, elem_is_int=False, normalise=NORM_NONE, damping=0.85):
+    """MatrixMarket -> (rows, cols, hdr_nnz, row_ptr, col_idx, val) with the reference's quirks;
+    normalise = NORM_PAGERANK / NORM_SCC applies the app's normaliser before the int narrowing."""
     rows, cols, hdr = C.c_int32(), C.c_int32(), C.c_int32()
     nnz = C.c_int64()
     rp, ci, va = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    rc = lib().oracle_mm_load(os.fsencode(path), C.c_int(int(elem_is_int)), C.byref(rows),
-                              C.byref(cols), C.byref(hdr), C.byref(nnz), C.byref(rp),
-                              C.byref(ci), C.byref(va))
+    rc = lib().oracle_mm_load_ex(os.fsencode(path), C.c_int(int(elem_is_int)), C.c_int(normalise),
+                                 C.c_double(damping), C.byref(rows), C.byref(cols), C.byref(hdr),
+                                 C.byref(nnz), C.byref(rp), C.byref(ci), C.byref(va))
     if rc != 0:
         raise RuntimeError(f"oracle_mm_load({path}) failed: {rc}")
     n = nnz.value
@@ -136,6 +140,8 @@ def initial_vector(semiring, n):
     elif semiring == OR_AND_I32:
         v = np.zeros(n, np.int32)
         v[0] = 1
+    elif semiring == MAX_MIN_I32:   # app/scc.cpp:176-185: x[i] = i (y0 is INT_MIN everywhere)
+        v = np.arange(n, dtype=np.int32)
     else:
         v = np.ones(n, np.float32)
     return v

@@ -10,7 +10,8 @@
 //   * SparseMatrix<T>::load_from_file / calculate_ellpack / cl_encode
 //       (/root/reference/src/sparse_matrix.cpp:11-119,122-399)
 //   * Gold<T>::spmv (/root/reference/inc/spmv_gold.h:9-28)
-//   * the Lift `glb-sdp` OpenCL kernels of example/{spmv,sssp,bfs}/kernel5.json,
+//   * SparseMatrix<T>::pagerank_normalise / scc_normalise (src/sparse_matrix.cpp:409-456)
+//   * the Lift `glb-sdp` OpenCL kernels of example/{spmv,sssp,bfs,pr,scc}/kernel5.json,
 //     compiled as C99 (oracle/ref/extract_kernels.py), fed with cl_encode's
 //     own ELLPACK buffers.
 // The iterative drivers below mirror the do/while loops of
@@ -37,6 +38,12 @@ void KERNEL_sssp(const int *idx, const float *val, const float *x,
                  const float *y, float alpha, float beta, float *out,
                  float *tmp, int MHeight, int MWidthC, int VLength);
 void KERNEL_bfs(const int *idx, const int *val, const int *x, const int *y,
+                int alpha, int beta, int *out, int *tmp, int MHeight,
+                int MWidthC, int VLength);
+void KERNEL_pr(const int *idx, const float *val, const float *x,
+               const float *y, float alpha, float beta, float *out,
+               float *tmp, int MHeight, int MWidthC, int VLength);
+void KERNEL_scc(const int *idx, const int *val, const int *x, const int *y,
                 int alpha, int beta, int *out, int *tmp, int MHeight,
                 int MWidthC, int VLength);
 }
@@ -247,6 +254,86 @@ int main(int argc, char **argv) {
     dump("bfs_meta", "i32", meta, 2);
     dump("bfs_first", "i32", first.data(), first.size());
     dump("bfs_final", "i32", pin->data(), pin->size());
+    delete enc;
+  }
+  // ---------------- PageRank: app/pr.cpp:179-215 (x = 1/N, y = 1, alpha = 1,
+  // beta = (1-d)/N, pagerank_normalise(0.85, 0) before encoding) -------------
+  {
+    SparseMatrix<float> m(file);
+    const float damping = 0.85f;
+    m.pagerank_normalise(damping, 0.0f);
+    dump_csr<float>(m, "pr", "f32");   // rows AFTER normalise + int narrowing (quirk A-3)
+    CL_matrix *enc;
+    {
+      StdoutMute mute;
+      enc = new CL_matrix(m.cl_encode(0xFFFFFFFFu, 0.0f, false, false, false, -1, -1));
+    }
+    int H = enc->cl_height, W = enc->cl_width;
+    const int *idx = reinterpret_cast<const int *>(enc->indices.data());
+    const float *val = reinterpret_cast<const float *>(enc->values.data());
+    std::vector<float> tmp((size_t)H * W);
+    ConstXVectorGenerator<float> x0(1.0f / (float)m.height());
+    ConstYVectorGenerator<float> y0(1.0f);
+    const float alpha = 1.0f, beta = (1.0f - damping) / (float)m.height();
+    std::vector<float> in = x0.generate(H), yv = y0.generate(H), o(H, 0.0f);
+    std::vector<float> *pin = &in, *pout = &o;
+    const float *ydev = yv.data();
+    const double delta = 0.0001;
+    int iters = 0;
+    bool term = false;
+    std::vector<float> first;
+    do {
+      KERNEL_pr(idx, val, pin->data(), ydev, alpha, beta, pout->data(), tmp.data(), H, W, H);
+      if (iters == 0) first = *pout;
+      bool equal = true; // app/pr.cpp:157-176
+      for (int i = 0; equal && i < H; i++) equal = fabs((*pin)[i] - (*pout)[i]) < delta;
+      term = equal;
+      std::swap(pin, pout);
+      ydev = pin->data();
+      iters++;
+    } while (!term && iters < ITER_CAP);
+    int meta[2] = {iters, term ? 1 : 0};
+    dump("pr_meta", "i32", meta, 2);
+    dump("pr_first", "f32", first.data(), first.size());
+    dump("pr_final", "f32", pin->data(), pin->size());
+    delete enc;
+  }
+  // ---------------- SCC: app/scc.cpp:179-251 (x[i] = i, y = INT_MIN, alpha = INT_MAX,
+  // beta = INT_MIN, zero = INT_MIN, scc_normalise() before encoding) --------------
+  {
+    SparseMatrix<int> m(file);
+    m.scc_normalise();
+    dump_csr<int>(m, "scc", "i32");
+    CL_matrix *enc;
+    {
+      StdoutMute mute;
+      enc = new CL_matrix(m.cl_encode(0xFFFFFFFFu, INT_MIN, false, false, false, -1, -1));
+    }
+    int H = enc->cl_height, W = enc->cl_width;
+    const int *idx = reinterpret_cast<const int *>(enc->indices.data());
+    const int *val = reinterpret_cast<const int *>(enc->values.data());
+    std::vector<int> tmp((size_t)H * W);
+    std::vector<int> in(H), yv(H, INT_MIN), o(H, 0);
+    for (int i = 0; i < H; i++) in[i] = i;   // InitialComponentsGeneratorX, app/scc.cpp:176-185
+    std::vector<int> *pin = &in, *pout = &o;
+    const int *ydev = yv.data();
+    int iters = 0;
+    bool term = false;
+    std::vector<int> first;
+    do {
+      KERNEL_scc(idx, val, pin->data(), ydev, INT_MAX, INT_MIN, pout->data(), tmp.data(), H, W, H);
+      if (iters == 0) first = *pout;
+      bool equal = true; // app/scc.cpp:154-172
+      for (int i = 0; equal && i < H; i++) equal = (*pin)[i] == (*pout)[i];
+      term = equal;
+      std::swap(pin, pout);
+      ydev = pin->data();
+      iters++;
+    } while (!term && iters < ITER_CAP);
+    int meta[2] = {iters, term ? 1 : 0};
+    dump("scc_meta", "i32", meta, 2);
+    dump("scc_first", "i32", first.data(), first.size());
+    dump("scc_final", "i32", pin->data(), pin->size());
     delete enc;
   }
   return 0;

@@ -28,7 +28,8 @@
 #define SH_ORACLE_ESIZE -4     /* src/sparse_matrix.cpp:36-39  -> returns   */
 #define SH_ORACLE_ENOMEM -5
 
-enum { SR_PLUS_TIMES_F32 = 0, SR_MIN_PLUS_F32 = 1, SR_OR_AND_I32 = 2 };
+enum { SR_PLUS_TIMES_F32 = 0, SR_MIN_PLUS_F32 = 1, SR_OR_AND_I32 = 2, SR_MAX_MIN_I32 = 3 };
+enum { NORM_NONE = 0, NORM_PAGERANK = 1, NORM_SCC = 2 };
 
 /* ------------------------------------------------------------------------
  * MatrixMarket -> CSR with the reference's exact semantics.
@@ -55,10 +56,15 @@ static void lower(char *p) {
     *p = (char)tolower((unsigned char)*p);
 }
 
-int oracle_mm_load(const char *path, int elem_is_int, int32_t *rows_out,
-                   int32_t *cols_out, int32_t *hdr_nnz_out, int64_t *nnz_out,
-                   int32_t **row_ptr_out, int32_t **col_idx_out,
-                   void **val_out) {
+/* normalise: NORM_PAGERANK restates SparseMatrix<float>::pagerank_normalise
+ * (src/sparse_matrix.cpp:409-431): column_sums[I] accumulated over the tuples in file order in T
+ * arithmetic, then val = (fabs(val) / column_sums[I]) * damping, the expression evaluated in
+ * double (::fabs(double) from <cmath>) and rounded to T once; NORM_SCC restates scc_normalise
+ * (:433-456): val = (I == J) ? numeric_limits<T>::min() : J.  Both act on the tuple list, i.e.
+ * BEFORE the int narrowing of calculate_ellpack (:107). */
+int oracle_mm_load_ex(const char *path, int elem_is_int, int normalise, double damping,
+                      int32_t *rows_out, int32_t *cols_out, int32_t *hdr_nnz_out, int64_t *nnz_out,
+                      int32_t **row_ptr_out, int32_t **col_idx_out, void **val_out) {
   FILE *f = fopen(path, "r");
   if (!f)
     return SH_ORACLE_EOPEN;
@@ -136,6 +142,25 @@ int oracle_mm_load(const char *path, int elem_is_int, int32_t *rows_out,
     }
   }
   fclose(f);
+  /* tuples hold static_cast<T>(val) (:59) */
+  for (size_t k = 0; k < n; k++)
+    tv[k] = elem_is_int ? (double)(int32_t)tv[k] : (double)(float)tv[k];
+  if (normalise == NORM_PAGERANK && !elem_is_int) {
+    float *sums = calloc((size_t)N + 1, sizeof(float));
+    if (!sums) return SH_ORACLE_ENOMEM;
+    for (size_t k = 0; k < n; k++)
+      sums[ti[k]] = sums[ti[k]] + (float)tv[k];
+    for (size_t k = 0; k < n; k++)
+      tv[k] = (double)(float)((fabs((double)(float)tv[k]) / sums[ti[k]]) * (float)damping);
+    free(sums);
+  } else if (normalise == NORM_SCC) {
+    for (size_t k = 0; k < n; k++) {
+      if (elem_is_int)
+        tv[k] = (ti[k] == tj[k]) ? (double)INT32_MIN : (double)tj[k];
+      else
+        tv[k] = (ti[k] == tj[k]) ? (double)1.17549435e-38f : (double)(float)tj[k];
+    }
+  }
   /* calculate_ellpack: histogram over get<1> (= J), rows sized by height() */
   int32_t *rp = calloc((size_t)M + 1, 4);
   int32_t *ci = malloc((n ? n : 1) * 4);
@@ -166,6 +191,14 @@ int oracle_mm_load(const char *path, int elem_is_int, int32_t *rows_out,
   *rows_out = M; *cols_out = N; *hdr_nnz_out = nz; *nnz_out = (int64_t)n;
   *row_ptr_out = rp; *col_idx_out = ci; *val_out = va;
   return SH_ORACLE_OK;
+}
+
+int oracle_mm_load(const char *path, int elem_is_int, int32_t *rows_out,
+                   int32_t *cols_out, int32_t *hdr_nnz_out, int64_t *nnz_out,
+                   int32_t **row_ptr_out, int32_t **col_idx_out,
+                   void **val_out) {
+  return oracle_mm_load_ex(path, elem_is_int, NORM_NONE, 0.0, rows_out, cols_out, hdr_nnz_out, nnz_out,
+                           row_ptr_out, col_idx_out, val_out);
 }
 
 void oracle_free(void *p) { free(p); }
@@ -231,6 +264,14 @@ static int32_t oa_epi(int32_t dp, int32_t alpha, int32_t y, int32_t beta) {
   return r1 || r2;
 }
 
+/* (max,min) of example/scc/kernel5.json:3: int_min, int_max, doubleMinMax */
+static int32_t mm_mult(int32_t a, int32_t b) { return a < b ? a : b; }
+static int32_t mm_add(int32_t a, int32_t b) { return a > b ? a : b; }
+static int32_t mm_epi(int32_t dp, int32_t alpha, int32_t y, int32_t beta) {
+  int32_t m1 = dp < alpha ? dp : alpha, m2 = y < beta ? y : beta;
+  return m1 > m2 ? m1 : m2;
+}
+
 /* ------------------------------------------------------------------------
  * One launch of the Lift `glb-sdp` kernel (example/<algo>/kernel5.json:3)
  * restated over CSR instead of the padded ELLPACK buffers:
@@ -248,6 +289,21 @@ int oracle_kernel(int semiring, int32_t rows, const int32_t *row_ptr,
                   const int32_t *col_idx, const void *val_, const void *x_,
                   const void *y_, const void *alpha_, const void *beta_,
                   int32_t vlength, void *out_) {
+  if (semiring == SR_MAX_MIN_I32) {   /* identity INT_MIN (app/scc.cpp:206); pads: max(acc, min(MIN,MIN)) = acc */
+    const int32_t *val = val_, *x = x_, *y = y_;
+    int32_t alpha = *(const int32_t *)alpha_, beta = *(const int32_t *)beta_;
+    int32_t *out = out_;
+    for (int32_t r = 0; r < rows; r++) {
+      int32_t acc = INT32_MIN;
+      for (int32_t j = row_ptr[r + 1] - 1; j >= row_ptr[r]; j--) {
+        int32_t c = col_idx[j];
+        int32_t xv = (c < 0 || c >= vlength) ? INT32_MIN : x[c];
+        acc = mm_add(acc, mm_mult(xv, val[j]));
+      }
+      out[r] = mm_epi(acc, alpha, y[r], beta);
+    }
+    return 0;
+  }
   if (semiring == SR_OR_AND_I32) {
     const int32_t *val = val_, *x = x_, *y = y_;
     int32_t alpha = *(const int32_t *)alpha_, beta = *(const int32_t *)beta_;
@@ -304,7 +360,8 @@ int oracle_kernel(int semiring, int32_t rows, const int32_t *row_ptr,
  * First launch uses the caller's y0; afterwards y aliases the input
  * (setGlobalArg(3, input_mem_ptr), app/sssp.cpp:150).
  * Termination: float semirings |in[i]-out[i]| < delta for all i
- * (app/sssp.cpp:170), int semiring in[i] == out[i] (app/bfs.cpp:167).
+ * (app/sssp.cpp:170, app/pr.cpp:170), int semirings in[i] == out[i]
+ * (app/bfs.cpp:167, app/scc.cpp:166).
  * `iters` counts launches including the confirming one.  max_iters bounds
  * graphs on which the reference would spin forever (TODO.md:7-8).
  * x0 is overwritten with the final vector (the buffer the reference's
@@ -325,7 +382,7 @@ int oracle_iterate(int semiring, int32_t rows, const int32_t *row_ptr,
     if (rc)
       return rc;
     int equal = 1;
-    if (semiring == SR_OR_AND_I32) {
+    if (semiring == SR_OR_AND_I32 || semiring == SR_MAX_MIN_I32) {
       const int32_t *a = in, *b = out;
       for (int32_t i = 0; equal && i < rows; i++)
         equal = a[i] == b[i];

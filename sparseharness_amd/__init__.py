@@ -10,4 +10,4 @@ Harness / Run / KernelConfig surface.
 There is no CPU compute path in this package.
 """
 from . import abi  # noqa: F401
-from .abi import MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401
+from .abi import MAX_MIN_I32, MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401

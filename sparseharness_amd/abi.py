@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SH_LIB") or os.path.join(_HERE, "libsparseharness_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 SH_OK, SH_EINVAL, SH_ENODEVICE, SH_EHIP, SH_ENOMEM, SH_ESHAPE = 0, -1, -2, -3, -4, -5
-PLUS_TIMES_F32, MIN_PLUS_F32, OR_AND_I32 = 0, 1, 2
+PLUS_TIMES_F32, MIN_PLUS_F32, OR_AND_I32, MAX_MIN_I32 = 0, 1, 2, 3
 
 
 class sh_launch(C.Structure):

@@ -786,6 +786,7 @@ static int dispatch(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec 
   case SH_PLUS_TIMES_F32: return launch_spmv<PlusTimesF32>(e, A, x, y, alpha, beta, out, st);
   case SH_MIN_PLUS_F32: return launch_spmv<MinPlusF32>(e, A, x, y, alpha, beta, out, st);
   case SH_OR_AND_I32: return launch_spmv<OrAndI32>(e, A, x, y, alpha, beta, out, st);
+  case SH_MAX_MIN_I32: return launch_spmv<MaxMinI32>(e, A, x, y, alpha, beta, out, st);
   default: return fail(e, SH_EINVAL, "unknown semiring %d", (int)sr);
   }
 }

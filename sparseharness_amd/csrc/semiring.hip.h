@@ -64,6 +64,23 @@ struct OrAndI32 {
   __device__ static inline bool differs(T in, T out, double) { return in != out; }
 };
 
+// (max,min) on int32: the SCC app (reference: example/scc/kernel5.json:3 -- int_min, int_max,
+// doubleMinMax; identity / padding value INT_MIN, app/scc.cpp:206).
+struct MaxMinI32 {
+  using T = int32_t;
+  static constexpr int id = 3;
+  __device__ static inline T identity() { return INT32_MIN; }
+  __device__ static inline T mul(T x, T a) { return x < a ? x : a; }       // int_min
+  __device__ static inline T add(T acc, T p) { return acc > p ? acc : p; } // int_max
+  __device__ static inline T epilogue(T dot, T alpha, T y, T beta, bool use_y) { // doubleMinMax
+    const T m1 = dot < alpha ? dot : alpha;
+    const T m2 = use_y ? (y < beta ? y : beta) : INT32_MIN;   // min(y, INT_MIN) == INT_MIN for every y
+    return m1 > m2 ? m1 : m2;
+  }
+  __host__ __device__ static inline bool reads_y(T beta) { return beta != INT32_MIN; }
+  __device__ static inline bool differs(T in, T out, double) { return in != out; }  // app/scc.cpp:166
+};
+
 template <class T> __device__ inline T from_bits(uint32_t u) {
   return __builtin_bit_cast(T, u);
 }

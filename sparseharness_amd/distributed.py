@@ -25,16 +25,16 @@ the oracle in instead to exercise the sharding + collective logic under gloo.
 import numpy as np
 
 from . import partition
-from .abi import MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401
+from .abi import MAX_MIN_I32, MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401
 
 
 def _torch_dtype(semiring):
     import torch
-    return torch.int32 if semiring == OR_AND_I32 else torch.float32
+    return torch.int32 if semiring in (OR_AND_I32, MAX_MIN_I32) else torch.float32
 
 
 def _np_dtype(semiring):
-    return np.int32 if semiring == OR_AND_I32 else np.float32
+    return np.int32 if semiring in (OR_AND_I32, MAX_MIN_I32) else np.float32
 
 
 class ShardPlan:

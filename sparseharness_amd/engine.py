@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401
+from .abi import MAX_MIN_I32, MIN_PLUS_F32, OR_AND_I32, PLUS_TIMES_F32  # noqa: F401
 
 FLT_MAX = np.float32(3.4028235e38)
 
@@ -21,7 +21,7 @@ class EngineError(RuntimeError):
 
 
 def elem_dtype(semiring):
-    return np.int32 if semiring == OR_AND_I32 else np.float32
+    return np.int32 if semiring in (OR_AND_I32, MAX_MIN_I32) else np.float32
 
 
 def _ptr(a):

@@ -21,6 +21,10 @@ Keys of each <name>.npz (all produced by reference code, see ref_driver.cpp):
   sssp_meta             [kernel launches incl. confirming one, converged?]
   sssp_first/final      vector after launch 1 / at termination
   bfs_meta, bfs_first/final   same for the (or,and) kernel
+  pr_row_ptr/col_idx/val      SparseMatrix<float> rows after pagerank_normalise(0.85, 0) (+ int narrowing)
+  pr_meta, pr_first/final     PageRank app loop on the Lift pr kernel (app/pr.cpp constants)
+  scc_row_ptr/col_idx/val     SparseMatrix<int> rows after scc_normalise()
+  scc_meta, scc_first/final   SCC app loop on the Lift (max,min) kernel (app/scc.cpp constants)
 """
 import glob
 import os

@@ -34,10 +34,12 @@ protected:
 struct BfsApp {
   using SemiRingType = int;
   using HarnessType = HarnessBFS;
-  static InitialDistancesGeneratorX<int> initialX() { return {1, 0}; }
-  static InitialDistancesGeneratorY<int> initialY() { return {1, 0}; }
-  static int alpha() { return 1; }
-  static int beta() { return 0; }
+  static void beforeLoad() {}
+  static void normalise(SparseMatrix<int> &) {}
+  static InitialDistancesGeneratorX<int> initialX(SparseMatrix<int> &) { return {1, 0}; }
+  static InitialDistancesGeneratorY<int> initialY(SparseMatrix<int> &) { return {1, 0}; }
+  static int alpha(SparseMatrix<int> &) { return 1; }
+  static int beta(SparseMatrix<int> &) { return 0; }
   static int zero() { return 0; }
   static std::string summarise(const std::vector<int> &f) {
     std::size_t set = 0;

@@ -1,4 +1,4 @@
-// iterative_app.h -- shared body of `sssp_harness` and `bfs_harness`.
+// iterative_app.h -- shared body of `sssp_harness`, `bfs_harness`, `pr_harness` and `scc_harness`.
 // Restates the flow of the reference's app/sssp.cpp:44-155 (and its twin
 // app/bfs.cpp:44-152): per trial, iterate  out = kernel(in, y)  until
 // should_terminate_iteration(in, out); swap in/out; y := in; then append the
@@ -128,17 +128,22 @@ inline bool env_host_loop() {
 }
 
 // Shared main(): `App` supplies the element type, the harness subclass and the
-// algorithm constants (initial vectors, alpha, beta, padding zero).
+// algorithm constants (initial vectors, alpha, beta, padding zero), each as a
+// function of the loaded matrix (PageRank's depend on its height), plus two
+// hooks: beforeLoad() runs ahead of the matrix load, normalise(matrix) right
+// before the encoding, where app/pr.cpp:199 and app/scc.cpp:217 call theirs.
 template <typename App> int iterative_main(int argc, char *argv[]) {
   using T = typename App::SemiRingType;
+  App::beforeLoad();
   COMMON_MAIN_PREAMBLE(T)
-  auto x = App::initialX();
-  auto y = App::initialY();
+  auto x = App::initialX(matrix);
+  auto y = App::initialY(matrix);
   unsigned long max_alloc = deviceGetMaxAllocSize(opt_platform->get(), opt_device->get());
   std::cout << "Got max alloc: " << max_alloc << "\n";
   ArgContainer<T> args;
   try {
-    args = executorEncodeMatrix(max_alloc, kernel, matrix, App::zero(), x, y, App::alpha(), App::beta());
+    App::normalise(matrix);
+    args = executorEncodeMatrix(max_alloc, kernel, matrix, App::zero(), x, y, App::alpha(matrix), App::beta(matrix));
   } catch (unsigned long attempted_alloc_size) {
     LOG_ERROR("Attempted to allocate: ", attempted_alloc_size, " bytes, but this device's max is ", max_alloc);
     return 1;

@@ -36,10 +36,12 @@ protected:
 struct SsspApp {
   using SemiRingType = float;
   using HarnessType = HarnessSSSP;
-  static InitialDistancesGeneratorX<float> initialX() { return {0.0f, std::numeric_limits<float>::max()}; }
-  static InitialDistancesGeneratorY<float> initialY() { return {0.0f, std::numeric_limits<float>::max()}; }
-  static float alpha() { return 0.0f; }
-  static float beta() { return 0.0f; }
+  static void beforeLoad() {}
+  static void normalise(SparseMatrix<float> &) {}
+  static InitialDistancesGeneratorX<float> initialX(SparseMatrix<float> &) { return {0.0f, std::numeric_limits<float>::max()}; }
+  static InitialDistancesGeneratorY<float> initialY(SparseMatrix<float> &) { return {0.0f, std::numeric_limits<float>::max()}; }
+  static float alpha(SparseMatrix<float> &) { return 0.0f; }
+  static float beta(SparseMatrix<float> &) { return 0.0f; }
   static float zero() { return std::numeric_limits<float>::max(); }
   static std::string summarise(const std::vector<float> &d) {
     std::size_t reached = 0;

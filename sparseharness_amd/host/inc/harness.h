@@ -26,11 +26,14 @@
 #include "run.h"
 #include "sql_stat.h"
 
-// (min,+) kernels carry clmin/absadd, (or,and) kernels bool_or/bool_and
-// (example/{sssp,bfs}/kernel5.json:3); everything else is (+,x).
+// (min,+) kernels carry clmin/absadd, (or,and) kernels bool_or/bool_and, (max,min) kernels
+// int_min/int_max (example/{sssp,bfs,scc}/kernel5.json:3); everything else -- spmv and
+// PageRank -- is (+,x).
 template <typename SemiRingType> inline sh_semiring detect_semiring(const std::string &kernel_source) {
   if (std::is_integral<SemiRingType>::value)
-    return SH_OR_AND_I32;
+    return kernel_source.find("int_max") != std::string::npos || kernel_source.find("doubleMinMax") != std::string::npos
+               ? SH_MAX_MIN_I32
+               : SH_OR_AND_I32;
   if (kernel_source.find("clmin") != std::string::npos || kernel_source.find("absadd") != std::string::npos)
     return SH_MIN_PLUS_F32;
   return SH_PLUS_TIMES_F32;

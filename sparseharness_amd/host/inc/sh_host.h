@@ -28,6 +28,11 @@ typedef struct sh_host_csr {
   void *val; /* float[nnz] or int32[nnz] */
 } sh_host_csr;
 int sh_mm_load(const char *path, int elem_is_int, int truncate_values, sh_host_csr *out);
+/* As sh_mm_load, then the app's matrix normaliser before the narrowing: normalise = 0 none,
+ * 1 SparseMatrix::pagerank_normalise(damping, 0) (app/pr.cpp:199), 2 scc_normalise()
+ * (app/scc.cpp:217). */
+int sh_mm_load_ex(const char *path, int elem_is_int, int truncate_values, int normalise, double damping,
+                  sh_host_csr *out);
 void sh_host_csr_release(sh_host_csr *m);
 
 #ifdef __cplusplus

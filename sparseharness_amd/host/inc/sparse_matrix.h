@@ -68,14 +68,29 @@ public:
   static void set_truncate(bool on) { truncate_flag() = on; }
   static bool truncate() { return truncate_flag(); }
 
+  // The apps' matrix normalisers (inc/sparse_matrix.h:60-62 of the reference).  Both rewrite the
+  // tuple values BEFORE the int narrowing of calculate_ellpack, as the reference does because it
+  // normalises nz_entries and builds the rows afterwards (app/pr.cpp:199, app/scc.cpp:217).
+  //   pagerank_normalise: val = (|val| / column_sums[I]) * damping, sums taken over the tuples in
+  //     file order in T arithmetic (src/sparse_matrix.cpp:409-431).  Needs the un-narrowed values
+  //     and the file order: load the matrix with set_keep_entries(true).
+  //   scc_normalise: val = (I == J) ? numeric_limits<T>::min() : J   (:433-456).
+  void pagerank_normalise(float dampingFactor, EType zero);
+  void scc_normalise();
+  // Keep what pagerank_normalise needs (8 bytes per entry); off by default.
+  static void set_keep_entries(bool on) { keep_flag() = on; }
+
 private:
   void load_from_file(const std::string &filename);
   static bool &truncate_flag();
+  static bool &keep_flag();
 
   int rows = 0, cols = 0, nonz = 0;
   unsigned int max_width = 0;
   std::vector<int32_t> row_ptr_, col_idx_;
   std::vector<EType> val_;
+  std::vector<EType> raw_val_;      // static_cast<T>(file value) in CSR order   } only with
+  std::vector<int32_t> file_order_; // CSR position of the k-th tuple            } keep_entries
   ellpack_matrix<EType> ellpack_cache_;
   bool ellpack_built_ = false;
 };

@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
+#include <limits>
+#include <stdexcept>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -147,12 +150,11 @@ struct Scanner {
   }
 };
 
-template <typename T> T narrow(double v, bool truncate);
-template <> float narrow<float>(double v, bool truncate) {
-  float f = static_cast<float>(v);
-  return truncate ? static_cast<float>(static_cast<int>(f)) : f;   // quirk A-3
-}
-template <> int narrow<int>(double v, bool) { return static_cast<int>(v); }
+// tuple value: static_cast<T>(val) (src/sparse_matrix.cpp:59)
+template <typename T> inline T tuple_value(double v) { return static_cast<T>(v); }
+// row value: the tuple value pushed through `int val` (:107, quirk A-3)
+inline float narrow(float f, bool truncate) { return truncate ? static_cast<float>(static_cast<int>(f)) : f; }
+inline int narrow(int i, bool) { return i; }
 
 } // namespace
 
@@ -164,6 +166,11 @@ template <typename T> bool &SparseMatrix<T>::truncate_flag() {
   return flag;
 }
 
+template <typename T> bool &SparseMatrix<T>::keep_flag() {
+  static bool flag = false;
+  return flag;
+}
+
 template <typename T> SparseMatrix<T>::SparseMatrix(std::string filename) { load_from_file(filename); }
 
 template <typename T>
@@ -171,6 +178,12 @@ SparseMatrix<T>::SparseMatrix(int r, int c, std::vector<int32_t> rp, std::vector
     : rows(r), cols(c), nonz((int)ci.size()), row_ptr_(std::move(rp)), col_idx_(std::move(ci)), val_(std::move(va)) {
   for (int i = 0; i < rows; i++)
     max_width = std::max<unsigned>(max_width, (unsigned)(row_ptr_[i + 1] - row_ptr_[i]));
+  if (keep_flag()) { // a generated matrix has no file: CSR order stands in for file order
+    raw_val_ = val_;
+    file_order_.resize(col_idx_.size());
+    for (std::size_t k = 0; k < file_order_.size(); k++)
+      file_order_[k] = (int32_t)k;
+  }
 }
 
 template <typename T> void SparseMatrix<T>::load_from_file(const std::string &filename) {
@@ -227,7 +240,7 @@ template <typename T> void SparseMatrix<T>::load_from_file(const std::string &fi
   ei.reserve(cap); ej.reserve(cap); ev.reserve(cap);
   auto emit = [&](int I, int J, double v) {
     --I; --J;
-    const T tv = narrow<T>(v, trunc);
+    const T tv = tuple_value<T>(v);
     ei.push_back(I); ej.push_back(J); ev.push_back(tv);
     if (b.symmetric && I != J) {
       ei.push_back(J); ej.push_back(I); ev.push_back(tv);
@@ -279,7 +292,7 @@ template <typename T> void SparseMatrix<T>::load_from_file(const std::string &fi
           ++ls.p;
         }
         if (!pt.ok) break;
-        pt.I.push_back(I - 1); pt.J.push_back(J - 1); pt.V.push_back(narrow<T>(v, trunc));
+        pt.I.push_back(I - 1); pt.J.push_back(J - 1); pt.V.push_back(tuple_value<T>(v));
         pt.out += (b.symmetric && I != J) ? 2 : 1;
       }
     }
@@ -334,7 +347,17 @@ template <typename T> void SparseMatrix<T>::load_from_file(const std::string &fi
   for (std::size_t k = 0; k < ej.size(); k++) {
     const int32_t pos = cursor[(std::size_t)ej[k]]++;
     col_idx_[(std::size_t)pos] = ei[k];
-    val_[(std::size_t)pos] = ev[k];
+    val_[(std::size_t)pos] = narrow(ev[k], trunc);
+  }
+  if (keep_flag()) {
+    raw_val_.resize(ej.size());
+    file_order_.resize(ej.size());
+    std::vector<int32_t> cur2(row_ptr_.begin(), row_ptr_.end() - 1);
+    for (std::size_t k = 0; k < ej.size(); k++) {
+      const int32_t pos = cur2[(std::size_t)ej[k]]++;
+      raw_val_[(std::size_t)pos] = ev[k];
+      file_order_[k] = pos;
+    }
   }
   LOG_DEBUG("max width: ", max_width);
 }
@@ -379,12 +402,58 @@ template <typename T> typename SparseMatrix<T>::template ellpack_matrix<T> &Spar
   return ellpack_cache_;
 }
 
+template <typename T> void SparseMatrix<T>::pagerank_normalise(float dampingFactor, T zero) {
+  start_timer(pagerank_normalise, sparse_matrix);
+  if (raw_val_.size() != col_idx_.size() || file_order_.size() != col_idx_.size()) {
+    LOG_ERROR("pagerank_normalise needs the file-order entries: call SparseMatrix::set_keep_entries(true) "
+              "before loading the matrix");
+    throw std::logic_error("pagerank_normalise without kept entries");
+  }
+  // column sums over the tuples in FILE order, in T arithmetic (:414-419); "column" is the
+  // tuple's first field, i.e. this layout's column index
+  std::vector<T> column_sums((std::size_t)width(), zero);
+  for (std::size_t k = 0; k < file_order_.size(); k++) {
+    const std::size_t pos = (std::size_t)file_order_[k];
+    const std::size_t x = (std::size_t)col_idx_[pos];
+    column_sums[x] = column_sums[x] + raw_val_[pos];
+  }
+  // (fabs(val) / column_sums[x]) * dampingFactor, evaluated as the reference's expression is:
+  // ::fabs(double), so the quotient and product are double and rounded to T once (:428)
+  const bool trunc = truncate();
+  for (std::size_t pos = 0; pos < raw_val_.size(); pos++) {
+    const T new_val =
+        static_cast<T>((std::fabs(static_cast<double>(raw_val_[pos])) / column_sums[(std::size_t)col_idx_[pos]]) *
+                       dampingFactor);
+    raw_val_[pos] = new_val;
+    val_[pos] = narrow(new_val, trunc);
+  }
+  ellpack_built_ = false;
+  ellpack_cache_.clear();
+}
+
+template <typename T> void SparseMatrix<T>::scc_normalise() {
+  start_timer(scc_normalise, sparse_matrix);
+  const bool trunc = truncate();
+  const bool keep = raw_val_.size() == col_idx_.size();
+  for (int r = 0; r < rows; r++)
+    for (int32_t k = row_ptr_[(std::size_t)r]; k < row_ptr_[(std::size_t)r + 1]; k++) {
+      // tuple (x, y) = (column, row) of this layout (:445-453)
+      const T nv = col_idx_[(std::size_t)k] == r ? std::numeric_limits<T>::min() : static_cast<T>(r);
+      if (keep)
+        raw_val_[(std::size_t)k] = nv;
+      val_[(std::size_t)k] = narrow(nv, trunc);
+    }
+  ellpack_built_ = false;
+  ellpack_cache_.clear();
+}
+
 template class SparseMatrix<float>;
 template class SparseMatrix<int>;
 
 // ---- C ABI for the Python side (sh_host.h) --------------------------------
-extern "C" int sh_mm_load(const char *path, int elem_is_int, int truncate_values, sh_host_csr *out) {
-  if (!path || !out)
+extern "C" int sh_mm_load_ex(const char *path, int elem_is_int, int truncate_values, int normalise, double damping,
+                             sh_host_csr *out) {
+  if (!path || !out || normalise < 0 || normalise > 2)
     return -1;
   auto fill = [&](auto &m) {
     out->rows = m.height(); out->cols = m.width(); out->header_nnz = m.nonZeros();
@@ -396,15 +465,27 @@ extern "C" int sh_mm_load(const char *path, int elem_is_int, int truncate_values
     std::memcpy(out->col_idx, m.colIdx().data(), sizeof(int32_t) * m.colIdx().size());
     std::memcpy(out->val, m.values().data(), 4 * m.values().size());
   };
-  if (elem_is_int) {
-    SparseMatrix<int> m{std::string(path)};
+  auto run = [&](auto tag) {
+    using M = SparseMatrix<decltype(tag)>;
+    M::set_truncate(truncate_values != 0);
+    M::set_keep_entries(normalise == 1);
+    M m{std::string(path)};
+    M::set_keep_entries(false);
+    if (normalise == 1)
+      m.pagerank_normalise((float)damping, 0);
+    else if (normalise == 2)
+      m.scc_normalise();
     fill(m);
-  } else {
-    SparseMatrix<float>::set_truncate(truncate_values != 0);
-    SparseMatrix<float> m{std::string(path)};
-    fill(m);
-  }
+  };
+  if (elem_is_int)
+    run(int{});
+  else
+    run(float{});
   return 0;
+}
+
+extern "C" int sh_mm_load(const char *path, int elem_is_int, int truncate_values, sh_host_csr *out) {
+  return sh_mm_load_ex(path, elem_is_int, truncate_values, 0, 0.0, out);
 }
 
 extern "C" void sh_host_csr_release(sh_host_csr *m) {

@@ -44,6 +44,8 @@ def load():
                                        C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.sh_mm_load.restype = C.c_int
         _lib.sh_mm_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(_HostCsr)]
+        _lib.sh_mm_load_ex.restype = C.c_int
+        _lib.sh_mm_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(_HostCsr)]
         _lib.sh_host_csr_release.restype = None
         _lib.sh_host_csr_release.argtypes = [C.POINTER(_HostCsr)]
     return _lib
@@ -83,10 +85,15 @@ def scircuit_like(seed=SEED_SCIRCUIT):
     return powerlaw(170_998, 958_936, dmax=353, seed=seed)
 
 
-def mm_load(path, elem_is_int=False, truncate=True):
-    """MatrixMarket -> (rows, cols, header_nnz, row_ptr, col_idx, val) through the product loader."""
+NORM_NONE, NORM_PAGERANK, NORM_SCC = 0, 1, 2
+
+
+def mm_load(path, elem_is_int=False, truncate=True, normalise=NORM_NONE, damping=0.85):
+    """MatrixMarket -> (rows, cols, header_nnz, row_ptr, col_idx, val) through the product loader;
+    normalise applies SparseMatrix::pagerank_normalise / scc_normalise as the pr / scc apps do."""
     m = _HostCsr()
-    rc = load().sh_mm_load(os.fsencode(path), int(elem_is_int), int(truncate), C.byref(m))
+    rc = load().sh_mm_load_ex(os.fsencode(path), int(elem_is_int), int(truncate), int(normalise), float(damping),
+                              C.byref(m))
     if rc:
         raise RuntimeError(f"sh_mm_load({path}) failed: {rc}")
     try:

@@ -61,3 +61,26 @@ def test_iterative_apps_match_reference(matrix_name, app, kernel, tag, host_loop
     sql = [l for l in r.stdout.splitlines() if l.startswith("INSERT INTO table_name")]
     assert len(sql) == 3                                    # one INSERT per trial
     assert sql[0].count("RAW_RESULT") == iters and "MULTI_ITERATION_SUM" in sql[0] and "MEDIAN_RESULT" in sql[0]
+
+
+@pytest.mark.parametrize("host_loop", ["0", "1"])
+@pytest.mark.parametrize("name", ["matrix2", "matrix3", "matrix4"])   # see tests/test_oracle.py PR_OK
+def test_pagerank_app_matches_reference(name, host_loop):
+    g = golden(name)
+    r = run_app("pr_harness", name, "pr.json", {"SH_HOST_LOOP": host_loop}, "-x", "2000")
+    assert r.returncode == 0, r.stderr[-800:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("SH_RESULT")][0]
+    assert f"iterations={int(g['pr_meta'][0])} converged={int(g['pr_meta'][1])}" in res
+    fin = g["pr_final"]
+    assert float(res.split("rank_sum=")[1].split()[0]) == pytest.approx(float(fin.astype(np.float64).sum()), rel=1e-6)
+
+
+@pytest.mark.parametrize("host_loop", ["0", "1"])
+def test_scc_app_matches_reference(matrix_name, host_loop):
+    g = golden(matrix_name)
+    r = run_app("scc_harness", matrix_name, "scc.json", {"SH_HOST_LOOP": host_loop}, "-x", "2000")
+    assert r.returncode == 0, r.stderr[-800:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("SH_RESULT")][0]
+    fin = g["scc_final"]
+    assert f"iterations={int(g['scc_meta'][0])} converged={int(g['scc_meta'][1])}" in res
+    assert f"labels={len(set(fin.tolist()))} label_sum={int(fin.astype(np.int64).sum())}" in res

@@ -35,13 +35,18 @@ class OracleLocalStep:
         out = O.kernel(self.semiring, p.row_ptr, p.col_idx, p.val.astype(dt), x, y, alpha, beta, vlength=lay.length)
         off = lay.slot_offset(p.rank)
         prev = x[off:off + p.rows]
-        if self.semiring == O.OR_AND_I32:
+        if self.semiring in (O.OR_AND_I32, O.MAX_MIN_I32):
             changed = bool((prev != out).any())
         else:
             changed = bool((~(np.abs(prev - out).astype(np.float64) < delta)).any())
         xn = x_next.numpy().view(dt)
         xn[off:off + p.rows] = out
         x_next.numpy().view(np.int32)[lay.flag_index(p.rank)] = int(changed)
+
+
+def initial_y(sr, x0):
+    """y0 of the app: x0 for sssp/bfs, INT_MIN everywhere for scc (app/scc.cpp:201-202)."""
+    return np.full(len(x0), O.INT_MIN, np.int32) if sr == O.MAX_MIN_I32 else x0
 
 
 def _free_port():
@@ -58,7 +63,8 @@ def _worker(rank, world, port, case, q):
         n = len(rp) - 1
         plan = ShardPlan(rp, ci, va, rank, world)
         x0 = O.initial_vector(sr, n)
-        final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, x0, a, b, 1e-4, 500)
+        final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, initial_y(sr, x0), a, b,
+                                                                                       1e-4, 500)
         q.put((rank, final, iters, conv))
     finally:
         dist.destroy_process_group()
@@ -86,25 +92,29 @@ def cases():
     g = golden("matrix")
     out["1138bus_sssp"] = (O.MIN_PLUS_F32, g["f32_row_ptr"], g["f32_col_idx"], g["f32_val"], 0.0, 0.0)
     out["1138bus_bfs"] = (O.OR_AND_I32, g["i32_row_ptr"], g["i32_col_idx"], g["i32_val"], 1, 0)
+    g5 = golden("matrix5")   # SCC on the reference's rows after scc_normalise (3 launches, 20 labels)
+    out["matrix5_scc"] = (O.MAX_MIN_I32, g5["scc_row_ptr"], g5["scc_col_idx"], g5["scc_val"], O.INT_MAX, O.INT_MIN)
     return out
 
 
-@pytest.mark.parametrize("name", ["rmat11_sssp", "rmat11_bfs", "1138bus_sssp", "1138bus_bfs"])
+@pytest.mark.parametrize("name", ["rmat11_sssp", "rmat11_bfs", "1138bus_sssp", "1138bus_bfs", "matrix5_scc"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_iteration_matches_single_process(name, world):
-    if world == 3 and not name.startswith("1138bus"):
+    if world == 3 and not name.startswith(("1138bus", "matrix5")):
         pytest.skip("3 ranks exercised on one graph only (keeps the CPU suite short)")
     case = cases()[name]
     sr, rp, ci, va, a, b = case
     n = len(rp) - 1
     x0 = O.initial_vector(sr, n)
-    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, x0, a, b, 1e-4, 500)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, initial_y(sr, x0), a, b, 1e-4, 500)
     res = run_world(world, case)
     for rank, final, iters, conv in res:
         assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
         np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
     if name == "1138bus_sssp":
         assert w_it == int(golden("matrix")["sssp_meta"][0])  # the real reference's iteration count
+    if name == "matrix5_scc":
+        np.testing.assert_array_equal(want, golden("matrix5")["scc_final"])
 
 
 def test_world1_driver_equals_oracle():

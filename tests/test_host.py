@@ -33,6 +33,33 @@ def test_product_loader_matches_reference_rows(matrix_name):
     np.testing.assert_array_equal(va, g["i32_val"])
 
 
+@pytest.mark.parametrize("name", ["matrix2", "matrix3", "matrix4"])   # see tests/test_oracle.py PR_OK
+def test_product_pagerank_normaliser_matches_reference_rows(name):
+    g = golden(name)
+    _, _, _, rp, ci, va = H.mm_load(mtx(name), normalise=H.NORM_PAGERANK, damping=0.85)
+    np.testing.assert_array_equal(rp, g["pr_row_ptr"])
+    np.testing.assert_array_equal(ci, g["pr_col_idx"])
+    np.testing.assert_array_equal(va.view(np.uint32), g["pr_val"].view(np.uint32))
+
+
+def test_product_scc_normaliser_matches_reference_rows(matrix_name):
+    g = golden(matrix_name)
+    _, _, _, rp, ci, va = H.mm_load(mtx(matrix_name), elem_is_int=True, normalise=H.NORM_SCC)
+    np.testing.assert_array_equal(rp, g["scc_row_ptr"])
+    np.testing.assert_array_equal(ci, g["scc_col_idx"])
+    np.testing.assert_array_equal(va, g["scc_val"])
+
+
+def test_pagerank_normaliser_without_truncation_is_column_stochastic():
+    # what the app was meant to compute (SH_NO_TRUNCATE): every column with entries sums to the damping factor
+    rows, cols, _, rp, ci, va = H.mm_load(mtx("matrix2"), truncate=False, normalise=H.NORM_PAGERANK, damping=0.85)
+    sums = np.bincount(ci, weights=va.astype(np.float64), minlength=cols)
+    has = np.bincount(ci, minlength=cols) > 0
+    np.testing.assert_allclose(sums[has], 0.85, rtol=1e-4)
+    # and the truncated (reference-faithful) load of the same file is all zeros, quirk A-3
+    assert not H.mm_load(mtx("matrix2"), normalise=H.NORM_PAGERANK)[5].any()
+
+
 def test_no_truncate_mode_keeps_real_values():
     _, _, _, rp, ci, va = H.mm_load(mtx("matrix"), truncate=False)
     assert abs(float(va[0]) - 1474.779) < 1e-2  # first entry of HB/1138_bus
@@ -71,7 +98,7 @@ def test_app_error_conventions(tmp_path):
 
 
 def test_shipped_kernel_configs_parse():
-    for k in ["spmv.json", "sssp.json", "bfs.json", "spmv_chunk128.json"]:
+    for k in ["spmv.json", "sssp.json", "bfs.json", "pr.json", "scc.json", "spmv_chunk128.json"]:
         d = json.load(open(os.path.join(KERNELS, k)))
         assert {"name", "source", "properties", "inputArgs", "outputArg", "tempGlobals", "tempLocals",
                 "paramVars"} <= set(d)

@@ -101,6 +101,36 @@ def test_iterative_apps_match_reference(eng, matrix_name, sr, tag, a, b):
     A.free()
 
 
+@pytest.mark.parametrize("name", ["matrix2", "matrix3", "matrix4"])   # see tests/test_oracle.py PR_OK
+def test_pagerank_matches_reference(eng, name):
+    g = golden(name)
+    rows, cols, _, rp, ci, va = H.mm_load(mtx(name), normalise=H.NORM_PAGERANK, damping=0.85)
+    x0 = np.full(rows, np.float32(1.0) / np.float32(rows), np.float32)
+    y0 = np.ones(rows, np.float32)
+    beta = (np.float32(1.0) - np.float32(0.85)) / np.float32(rows)
+    A = eng.upload_csr(rows, cols, rp, ci, va)
+    xv, yv, out = eng.vector(x0), eng.vector(y0), eng.alloc(rows).fill(0)
+    eng.spmv(O.PLUS_TIMES_F32, A, xv, yv, 1.0, beta, out)
+    np.testing.assert_array_equal(bits(out.download(np.float32)), bits(g["pr_first"]))
+    iters, conv, _, _ = eng.iterate(O.PLUS_TIMES_F32, A, xv, yv, out, 1.0, beta, delta=1e-4, max_iters=2000)
+    assert [iters, int(conv)] == g["pr_meta"].tolist()
+    np.testing.assert_array_equal(bits(xv.download(np.float32)), bits(g["pr_final"]))
+
+
+def test_scc_matches_reference(eng, matrix_name):
+    g = golden(matrix_name)
+    rows, cols, _, rp, ci, va = H.mm_load(mtx(matrix_name), elem_is_int=True, normalise=H.NORM_SCC)
+    x0 = O.initial_vector(O.MAX_MIN_I32, rows)
+    y0 = np.full(rows, O.INT_MIN, np.int32)
+    A = eng.upload_csr(rows, cols, rp, ci, va)
+    xv, yv, out = eng.vector(x0), eng.vector(y0), eng.alloc(rows).fill(0)
+    eng.spmv(O.MAX_MIN_I32, A, xv, yv, O.INT_MAX, O.INT_MIN, out)
+    np.testing.assert_array_equal(out.download(np.int32), g["scc_first"])
+    iters, conv, _, _ = eng.iterate(O.MAX_MIN_I32, A, xv, yv, out, O.INT_MAX, O.INT_MIN, delta=1e-4, max_iters=2000)
+    assert [iters, int(conv)] == g["scc_meta"].tolist()
+    np.testing.assert_array_equal(xv.download(np.int32), g["scc_final"])
+
+
 # ------------------------------------------------------------------ (b) oracle on seeded synthetic inputs
 def synth_cases():
     rng = np.random.default_rng(1234)
@@ -157,6 +187,61 @@ def test_semiring_variants_match_oracle(eng, cases, name, sr):
     a2, b2 = (2.0, 1.0) if sr == O.MIN_PLUS_F32 else (1, 1)
     got = run_spmv(eng, sr, rp, ci, vals, x, y, a2, b2)
     np.testing.assert_array_equal(bits(got), bits(O.kernel(sr, rp, ci, vals, x, y, a2, b2)))
+
+
+def scc_values(rp, ci):
+    """scc_normalise on a CSR: the row index off the diagonal, INT_MIN on it (src/sparse_matrix.cpp:433-456)."""
+    row_of = np.repeat(np.arange(len(rp) - 1, dtype=np.int32), np.diff(rp))
+    return np.where(ci == row_of, np.int32(O.INT_MIN), row_of).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])
+def test_max_min_semiring_matches_oracle(eng, cases, name):
+    rp, ci, va, n = cases[name]
+    vals = scc_values(rp, ci)
+    x0 = O.initial_vector(O.MAX_MIN_I32, n)
+    y0 = np.full(n, O.INT_MIN, np.int32)
+    got = run_spmv(eng, O.MAX_MIN_I32, rp, ci, vals, x0, y0, O.INT_MAX, O.INT_MIN)
+    np.testing.assert_array_equal(got, O.kernel(O.MAX_MIN_I32, rp, ci, vals, x0, y0, O.INT_MAX, O.INT_MIN))
+    # general alpha/beta/y, negative labels included
+    rng = np.random.default_rng(5)
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    y = rng.integers(-1000, 1000, n).astype(np.int32)
+    v2 = rng.integers(-1000, 1000, len(ci)).astype(np.int32)
+    for a2, b2 in ((500, -200), (O.INT_MAX, O.INT_MAX), (-5, O.INT_MIN)):
+        got = run_spmv(eng, O.MAX_MIN_I32, rp, ci, v2, x, y, a2, b2)
+        np.testing.assert_array_equal(got, O.kernel(O.MAX_MIN_I32, rp, ci, v2, x, y, a2, b2))
+
+
+def test_scc_iterate_matches_oracle_on_rmat(eng, cases):
+    rp, ci, va, n = cases["rmat15"]
+    vals = scc_values(rp, ci)
+    x0 = O.initial_vector(O.MAX_MIN_I32, n)
+    y0 = np.full(n, O.INT_MIN, np.int32)
+    want, w_it, w_conv = O.iterate(O.MAX_MIN_I32, rp, ci, vals, x0, y0, O.INT_MAX, O.INT_MIN, max_iters=80)
+    A = eng.upload_csr(n, n, rp, ci, vals)
+    xv, yv, sc = eng.vector(x0), eng.vector(y0), eng.alloc(n).fill(0)
+    iters, conv, _, _ = eng.iterate(O.MAX_MIN_I32, A, xv, yv, sc, O.INT_MAX, O.INT_MIN, delta=1e-4, max_iters=80)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(xv.download(np.int32), want)
+
+
+def test_pagerank_iterate_tracks_oracle_on_rmat(eng, cases):
+    """The PageRank the app was meant to run (no int narrowing): column-stochastic weights x damping.
+    Floating-point sums reassociate on the GPU, so the vectors agree to 1e-5 relative, not bitwise."""
+    rp, ci, va, n = cases["rmat15"]
+    sums = np.bincount(ci, weights=va.astype(np.float64), minlength=n)
+    vals = (np.abs(va) / sums[ci] * 0.85).astype(np.float32)
+    x0 = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+    y0 = np.ones(n, np.float32)
+    beta = (np.float32(1.0) - np.float32(0.85)) / np.float32(n)
+    delta = 1e-9
+    want, w_it, w_conv = O.iterate(O.PLUS_TIMES_F32, rp, ci, vals, x0, y0, 1.0, beta, delta=delta, max_iters=200)
+    A = eng.upload_csr(n, n, rp, ci, vals)
+    xv, yv, sc = eng.vector(x0), eng.vector(y0), eng.alloc(n).fill(0)
+    iters, conv, _, _ = eng.iterate(O.PLUS_TIMES_F32, A, xv, yv, sc, 1.0, beta, delta=delta, max_iters=200)
+    assert conv and w_conv and abs(iters - w_it) <= 2 and iters > 5
+    np.testing.assert_allclose(xv.download(np.float32), want, rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])

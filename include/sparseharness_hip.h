@@ -117,6 +117,11 @@ int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
  * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM).
  * streamed_bytes = HBM bytes one SpMV moves by construction under that plan. */
 int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
+/* One-line description of the layout built at upload, for logs and bench records, e.g.
+ * "tiled values=dict8(16) tiles=306 chunks=6416 bins=8532 heavy_rows=5276 stream=200.9M light=138.3M".
+ * values=dict8(k): the matrix has k <= 256 distinct 4-byte values and the tiled stream carries
+ * one-byte codes (lossless; SH_VALCODE=off keeps raw values); values=raw otherwise. */
+int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen);
 
 /* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /
  *      writeToGlobalArg / fillGlobalArg / readFromGlobalArg

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sh_csr_dims": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sh_csr_algorithmic_bytes": (_int, [_vp, _int, C.POINTER(_u64)]),
     "sh_csr_plan": (_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
+    "sh_csr_describe": (_int, [_vp, C.c_char_p, C.c_size_t]),
     "sh_vec_alloc": (_int, [_vp, _i64, _pp]),
     "sh_vec_wrap": (_int, [_vp, _vp, _i64, _pp]),
     "sh_vec_free": (_int, [_vp, _vp]),

@@ -52,6 +52,10 @@ struct sh_csr {
   TileChunk *d_chunks = nullptr;
   int32_t n_chunks = 0;
   uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gsrc = nullptr, *d_P = nullptr;
+  uint8_t *d_tcode = nullptr;    // value coding: one-byte dictionary codes instead of d_tval
+  uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
+  int n_vdict = 0;               // 0 = values stored raw
+  int n_vdict_used = 0;          // distinct values found (<= VDICT)
   int p_stream_order = 0; // 1: P in tile-major stream order (phase 2 gathers pieces); 0: bin-major
   uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
   LongRow *d_tlong = nullptr;   // heavy rows (pre-reduced in phase 1)
@@ -248,6 +252,9 @@ struct TiledHost {
   std::vector<TileChunk> chunks;
   std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
   std::vector<uint32_t> tval, gdest, gsrc, lrp;
+  std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
+  std::vector<uint32_t> vdict;       // empty = raw values
+  int vdict_used = 0;
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0, light_len = 0;
   int32_t n_partials = 0;
@@ -364,8 +371,38 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     H.n_partials = (int32_t)acc;
   }
 
+  // value dictionary: <= VDICT distinct bit patterns (code 0 = the all-zero word, used by padding)
+  // => the stream carries one-byte codes.  SH_VALCODE=off keeps raw values.
+  constexpr uint32_t VH = 2048, VEMPTY = 0xFFFFFFFFu;
+  std::vector<uint32_t> hkey(VH, 0u), hcode(VH, VEMPTY);
+  auto vhash = [](uint32_t b) { return (b * 2654435761u) >> 21; };   // 11 bits
+  auto vfind = [&](uint32_t b) -> uint32_t {   // slot holding b, or the empty slot where it belongs
+    uint32_t h = vhash(b);
+    while (hcode[h] != VEMPTY && hkey[h] != b) h = (h + 1) & (VH - 1);
+    return h;
+  };
+  {
+    const char *vc = getenv("SH_VALCODE");
+    bool coded = !(vc && !strcmp(vc, "off"));
+    if (coded) {
+      H.vdict.assign(1, 0u);
+      hkey[vfind(0u)] = 0u; hcode[vfind(0u)] = 0u;
+      for (int64_t j = 0; j < nnz && coded; j++) {
+        const uint32_t h = vfind(val[j]);
+        if (hcode[h] == VEMPTY) {
+          if (H.vdict.size() == (size_t)VDICT) { coded = false; break; }
+          hkey[h] = val[j]; hcode[h] = (uint32_t)H.vdict.size();
+          H.vdict.push_back(val[j]);
+        }
+      }
+    }
+    if (!coded) H.vdict.clear();
+  }
+  const bool coded = !H.vdict.empty();
+
   // 3. sweep B: same walks, now filling the arrays
-  H.tval.assign((size_t)H.stream_len, 0u);
+  if (coded) { H.vdict_used = (int)H.vdict.size(); H.tcode.assign((size_t)H.stream_len, 0); H.vdict.resize(VDICT, 0u); }
+  else H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)H.stream_len / 4, 0u);
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
@@ -375,7 +412,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
     const bool in_range = (uint32_t)c < (uint32_t)cols;
-    H.tval[(size_t)pos] = val[j];
+    if (coded) H.tcode[(size_t)pos] = (uint8_t)hcode[vfind(val[j])];
+    else H.tval[(size_t)pos] = val[j];
     H.tcol[(size_t)pos] = in_range ? (uint16_t)(c & (TCOLS - 1)) : TCOL_IDENTITY;
   };
   for (auto &b : H.bins) {
@@ -545,8 +583,17 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     HIP_TRY_M(hipMemcpyAsync(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_chunks, th.chunks.size() * sizeof(TileChunk)));
     HIP_TRY_M(hipMemcpyAsync(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_tval, th.tval.size() * 4 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_tval, th.tval.data(), th.tval.size() * 4, hipMemcpyHostToDevice, e->stream));
+    if (!th.vdict.empty()) {
+      m->n_vdict = (int)th.vdict.size();
+      m->n_vdict_used = th.vdict_used;
+      HIP_TRY_M(hipMalloc((void **)&m->d_tcode, th.tcode.size() + 64));
+      HIP_TRY_M(hipMemcpyAsync(m->d_tcode, th.tcode.data(), th.tcode.size(), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_vdict, th.vdict.size() * 4));
+      HIP_TRY_M(hipMemcpyAsync(m->d_vdict, th.vdict.data(), th.vdict.size() * 4, hipMemcpyHostToDevice, e->stream));
+    } else {
+      HIP_TRY_M(hipMalloc((void **)&m->d_tval, th.tval.size() * 4 + 16));
+      HIP_TRY_M(hipMemcpyAsync(m->d_tval, th.tval.data(), th.tval.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
     HIP_TRY_M(hipMalloc((void **)&m->d_tcol, th.tcol.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
@@ -591,7 +638,8 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
-                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp})
+                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
+                  (void *)m->d_tcode, (void *)m->d_vdict})
     if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
@@ -621,9 +669,26 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
   if (streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
-                          ? 7ull * m->stream_len + 4ull * m->light_len /* phase 1 */ + 7ull * m->light_len /* phase 2 */ +
+                          ? (m->n_vdict ? 3ull : 6ull) * m->stream_len + (uint64_t)(m->stream_len - m->light_len) /* gdest */ +
+                                4ull * m->light_len /* phase 1 */ + 7ull * m->light_len /* phase 2 */ +
                                 vec + 128ull * 1024 * m->n_chunks /* x tile per phase-1 workgroup (mostly L2) */
                           : 8ull * m->nnz + vec;
+  }
+  return SH_OK;
+}
+
+int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
+  if (!m || !buf || buflen == 0)
+    return SH_EINVAL;
+  if (m->plan == PLAN_TILED) {
+    char vals[32];
+    if (m->n_vdict) snprintf(vals, sizeof vals, "dict8(%d)", m->n_vdict_used);
+    else snprintf(vals, sizeof vals, "raw");
+    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM", vals,
+             (long long)((m->cols + TCOLS - 1) >> TCOLS_LOG2), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
+             m->light_len / 1e6);
+  } else {
+    snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);
   }
   return SH_OK;
 }
@@ -733,9 +798,14 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
   if (A->plan == PLAN_TILED) {
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
-                       A->d_chunks, A->d_tval, A->d_tcol, A->d_gdest, (const uint32_t *)x->d, (int32_t)A->cols,
-                       A->d_P, A->p_stream_order, A->d_tpartial);
+    if (A->n_vdict)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, true>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+                         A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
+                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->p_stream_order, A->d_tpartial);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, false>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+                         A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
+                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->p_stream_order, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
                        e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, A->d_pslot,

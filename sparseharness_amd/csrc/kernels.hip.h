@@ -20,6 +20,7 @@
 //
 // HBM-bound (0.23 flop/B): no MFMA by design.
 #pragma once
+#include <type_traits>
 #include "semiring.hip.h"
 
 namespace sh {
@@ -378,20 +379,38 @@ struct TileChunk { int32_t tile, s, e, hs; };
 // long row and its result goes to partial[pslot].
 struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, pslot, pad; };
 
-template <class SR>
+// Value coding (VC): when the matrix holds at most 256 distinct 4-byte values (always true for
+// pattern files, and for every file once the reference's int narrowing -- quirk A-3 -- has been
+// applied to small weights) the tile-major stream carries one-byte dictionary codes instead of the
+// values: 3 instead of 6 bytes per entry read by phase 1.  Lossless: dict[code] is the original
+// bit pattern; code 0 is always the all-zero word (padding).
+#ifndef SH_P1_UNROLL_VC
+#define SH_P1_UNROLL_VC 4
+#endif
+constexpr int P1U_VC = SH_P1_UNROLL_VC;
+constexpr int VDICT = 256;
+
+template <class SR, bool VC>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
-    const TileChunk *__restrict__ chunks, const uint32_t *__restrict__ tval,
+    const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
+    const uint32_t *__restrict__ vdict,
     const uint16_t *__restrict__ tcol, const uint32_t *__restrict__ gdest,
     const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P, int p_in_stream_order,
     uint32_t *__restrict__ partial) {
   using T = typename SR::T;
+  constexpr int U = VC ? P1U_VC : P1U;
+  using VWord = typename std::conditional<VC, uint32_t, uint4>::type;   // 4 codes or 4 values
   __shared__ uint32_t xs[TCOLS];
+  __shared__ uint32_t ds[VC ? VDICT : 1];
+  const VWord *tval = reinterpret_cast<const VWord *>(tval_or_code);
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e)
     return;   // filler that keeps the XCD-aligned chunk order
   const int tid = threadIdx.x;
   const int c0 = ch.tile << TCOLS_LOG2;
   const uint32_t ident = to_bits<T>(SR::identity());
+  if (VC && tid < VDICT)
+    ds[tid] = vdict[tid];
   // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
   if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     for (int i = tid; i < TCOLS / 4; i += TBS)   // full tile, 16-byte aligned: 1 KiB per wave-instruction
@@ -401,29 +420,36 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
       xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
   }
   __syncthreads();
+  auto values = [&](const VWord &w) -> uint4 {
+    if constexpr (VC)
+      return make_uint4(ds[w & 0xFFu], ds[(w >> 8) & 0xFFu], ds[(w >> 16) & 0xFFu], ds[w >> 24]);
+    else
+      return w;
+  };
   // ---- light entries: products go to P (sequential 16-byte stores in stream-order layout)
   const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
-  for (int g0 = ch.s / 4 + tid; g0 < le; g0 += TBS * P1U) {
-    uint4 v[P1U];
-    uint2 c[P1U];
-    uint32_t d[P1U];
+  for (int g0 = ch.s / 4 + tid; g0 < le; g0 += TBS * U) {
+    VWord vw[U];
+    uint2 c[U];
+    uint32_t d[U];
 #pragma unroll
-    for (int k = 0; k < P1U; k++) {   // unconditional loads on clamped indices: one basic block
+    for (int k = 0; k < U; k++) {   // unconditional loads on clamped indices: one basic block
       const int g = min(g0 + k * TBS, le - 1);
-      v[k] = reinterpret_cast<const uint4 *>(tval)[g];
+      vw[k] = tval[g];
       c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
       d[k] = p_in_stream_order ? (uint32_t)g * 4u : gdest[g];
     }
 #pragma unroll
-    for (int k = 0; k < P1U; k++) {
+    for (int k = 0; k < U; k++) {
       const int g = g0 + k * TBS;
       if (g < le) {
         const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
+        const uint4 v = values(vw[k]);
         uint4 p;
-        p.x = to_bits<T>(SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v[k].x)));
-        p.y = to_bits<T>(SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v[k].y)));
-        p.z = to_bits<T>(SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v[k].z)));
-        p.w = to_bits<T>(SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v[k].w)));
+        p.x = to_bits<T>(SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v.x)));
+        p.y = to_bits<T>(SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v.y)));
+        p.z = to_bits<T>(SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v.z)));
+        p.w = to_bits<T>(SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v.w)));
         *reinterpret_cast<uint4 *>(P + d[k]) = p;
       }
     }
@@ -436,29 +462,30 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   const int hb = max(ch.s, min(ch.e, ch.hs)) / 4, he = ch.e / 4;
   const int lane = tid & 63;
   // start on the 64-group boundary (relative to the chunk start) the builder assumed
-  for (int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid; g0 < he; g0 += TBS * P1U) {
-    uint4 v[P1U];
-    uint2 c[P1U];
-    uint32_t d[P1U];
+  for (int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid; g0 < he; g0 += TBS * U) {
+    VWord vw[U];
+    uint2 c[U];
+    uint32_t d[U];
 #pragma unroll
-    for (int k = 0; k < P1U; k++) {
+    for (int k = 0; k < U; k++) {
       const int g = max(hb, min(g0 + k * TBS, he - 1));
-      v[k] = reinterpret_cast<const uint4 *>(tval)[g];
+      vw[k] = tval[g];
       c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
       d[k] = gdest[g];
     }
 #pragma unroll
-    for (int k = 0; k < P1U; k++) {
+    for (int k = 0; k < U; k++) {
       const int g = g0 + k * TBS;
       const bool valid = g >= hb && g < he;
       if (__ballot(valid)) {   // wave-uniform
         T t = SR::identity();
         if (valid) {
           const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
-          t = SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v[k].x));
-          t = SR::add(t, SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v[k].y)));
-          t = SR::add(t, SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v[k].z)));
-          t = SR::add(t, SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v[k].w)));
+          const uint4 v = values(vw[k]);
+          t = SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v.x));
+          t = SR::add(t, SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v.y)));
+          t = SR::add(t, SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v.z)));
+          t = SR::add(t, SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v.w)));
         }
         const uint32_t key = valid ? d[k] : (0x80000000u | (uint32_t)lane);   // invalid lanes never merge
 #pragma unroll

@@ -82,6 +82,12 @@ class CsrMatrix:
         self.engine._chk(abi.load().sh_csr_plan(self.h, C.byref(p), C.byref(b)))
         return ("stream", "tiled")[p.value], b.value
 
+    def describe(self):
+        """One-line description of the device layout (plan, value coding, tile/bin counts)."""
+        buf = C.create_string_buffer(256)
+        self.engine._chk(abi.load().sh_csr_describe(self.h, buf, len(buf)))
+        return buf.value.decode()
+
     def free(self):
         if self.h is not None:
             abi.load().sh_csr_free(self.engine.h, self.h)

@@ -27,11 +27,13 @@ def eng():
     e.close()
 
 
-@pytest.fixture(params=["stream", "tiled"], autouse=True)
+@pytest.fixture(params=["stream", "tiled", "tiled-raw"], autouse=True)
 def plan(request, monkeypatch):
-    """Every parity test runs under both execution plans of the engine."""
-    monkeypatch.setenv("SH_PLAN", request.param)
-    return request.param
+    """Every parity test runs under both execution plans of the engine; the tiled plan with its
+    one-byte value coding (taken whenever the matrix has <= 256 distinct values) and without."""
+    monkeypatch.setenv("SH_PLAN", request.param.split("-")[0])
+    monkeypatch.setenv("SH_VALCODE", "off" if request.param.endswith("raw") else "auto")
+    return request.param.split("-")[0]
 
 
 def bits(a):
@@ -257,6 +259,43 @@ def test_iterate_matches_oracle_on_rmat(eng, cases, sr):
     iters, conv, _, _ = eng.iterate(sr, A, xv, yv, sc, a, b, delta=1e-4, max_iters=60)
     assert (iters, conv) == (w_it, w_conv)
     np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
+
+
+def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
+    """<= 256 distinct values -> one-byte codes in the tiled stream; more -> raw values; always lossless."""
+    if plan != "tiled":
+        pytest.skip("value coding belongs to the tiled plan")
+    monkeypatch.setenv("SH_VALCODE", "auto")
+    rp, ci, va, n = cases["powerlaw_int"]
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert "values=dict8(17)" in A.describe()        # weights 1..16 plus the padding word 0
+    A.free()
+    rp, ci, va, n = cases["powerlaw_real"]
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert "values=raw" in A.describe()
+    A.free()
+    # exactly 255 distinct non-zero bit patterns (incl. -0.0, inf, a NaN payload) still fit; 256 do not
+    rng = np.random.default_rng(11)
+    m, nnz = 4096, 200_000
+    rp = np.linspace(0, nnz, m + 1).astype(np.int32)
+    ci = rng.integers(0, m, nnz).astype(np.int32)
+    pool = np.concatenate([np.array([0x80000000, 0x7F800000, 0x7FC00123], np.uint32),
+                           rng.integers(1, 2**31, 252).astype(np.uint32)])
+    for k, want in ((255, "dict8(256)"), (256, "raw")):
+        vb = np.unique(np.concatenate([pool, np.array([0x12345678], np.uint32)]))[:k]
+        assert len(vb) == k
+        vals = vb[rng.integers(0, k, nnz)]
+        vals[:k] = vb
+        A = eng.upload_csr(m, m, rp, ci, vals.view(np.float32))
+        assert f"values={want}" in A.describe()
+        x = rng.integers(0, 2, m).astype(np.int32)    # (or,and) on raw words: exact whatever the bits mean
+        xv, out = eng.vector(x), eng.alloc(m).fill(0)
+        eng.spmv(O.OR_AND_I32, A, xv, None, 1, 0, out)
+        np.testing.assert_array_equal(out.download(np.int32),
+                                      O.kernel(O.OR_AND_I32, rp, ci, vals.view(np.int32), x, x, 1, 0))
+        for v in (xv, out):
+            v.free()
+        A.free()
 
 
 def test_rectangular_and_wide_matrices(eng):

@@ -56,7 +56,6 @@ struct sh_csr {
   uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
   int n_vdict = 0;               // 0 = values stored raw
   int n_vdict_used = 0;          // distinct values found (<= VDICT)
-  int p_stream_order = 0; // 1: P in tile-major stream order (phase 2 gathers pieces); 0: bin-major
   uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
   LongRow *d_tlong = nullptr;   // heavy rows (pre-reduced in phase 1)
   int32_t n_tlong = 0;
@@ -427,7 +426,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       piece_stream[t] = cursor[t];
       piece_p[t] = off;
       for (int32_t q = 0; q < padded; q += 4) {
-        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)(off + q);      // bin-major P position (debug layout)
         H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(cursor[t] + q);
       }
       cursor[t] += padded;
@@ -598,14 +596,8 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, hipMemcpyHostToDevice, e->stream));
-    {
-      const char *lay = getenv("SH_TILED_LAYOUT");
-      m->p_stream_order = (lay && !strcmp(lay, "binmajor")) ? 0 : 1;
-    }
-    if (m->p_stream_order) {
-      HIP_TRY_M(hipMalloc((void **)&m->d_gsrc, th.gsrc.size() * 4 + 16));
-      HIP_TRY_M(hipMemcpyAsync(m->d_gsrc, th.gsrc.data(), th.gsrc.size() * 4, hipMemcpyHostToDevice, e->stream));
-    }
+    HIP_TRY_M(hipMalloc((void **)&m->d_gsrc, th.gsrc.size() * 4 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_gsrc, th.gsrc.data(), th.gsrc.size() * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max(th.p_len, th.stream_len) * 4 + 16));
@@ -801,15 +793,15 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     if (A->n_vdict)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, true>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                          A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->p_stream_order, A->d_tpartial);
+                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, false>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
-                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->p_stream_order, A->d_tpartial);
+                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
                        e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, A->d_pslot,
-                       A->p_stream_order ? A->d_gsrc : nullptr, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+                       A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());
     if (A->n_tlong > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,

@@ -367,8 +367,9 @@ constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #endif
 constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
-constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 marker: x reads as the identity
+constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 code of "x reads as the identity": == TCOLS, the LDS slot holding it
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
+static_assert(TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
 constexpr uint32_t THEAVY = 0x80000000u;   // gdest flag: group belongs to a heavy row, low bits = partial slot
 
 // entries [s,e) of the tile-major stream; positions >= hs belong to heavy rows (each tile's stream
@@ -393,16 +394,17 @@ constexpr int VDICT = 256;
 template <class SR, bool VC>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
-    const uint32_t *__restrict__ vdict,
-    const uint16_t *__restrict__ tcol, const uint32_t *__restrict__ gdest,
-    const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ P, int p_in_stream_order,
-    uint32_t *__restrict__ partial) {
+    const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
+    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
   using VWord = typename std::conditional<VC, uint32_t, uint4>::type;   // 4 codes or 4 values
-  __shared__ uint32_t xs[TCOLS];
+  // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
+  __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC ? VDICT : 1];
-  const VWord *tval = reinterpret_cast<const VWord *>(tval_or_code);
+  const VWord *__restrict__ tval = reinterpret_cast<const VWord *>(tval_or_code);
+  const uint2 *__restrict__ tcol2 = reinterpret_cast<const uint2 *>(tcol);
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e)
     return;   // filler that keeps the XCD-aligned chunk order
@@ -411,6 +413,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   const uint32_t ident = to_bits<T>(SR::identity());
   if (VC && tid < VDICT)
     ds[tid] = vdict[tid];
+  if (tid == 0)
+    xs[TCOLS] = ident;
   // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
   if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     for (int i = tid; i < TCOLS / 4; i += TBS)   // full tile, 16-byte aligned: 1 KiB per wave-instruction
@@ -420,37 +424,61 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
       xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
   }
   __syncthreads();
-  auto values = [&](const VWord &w) -> uint4 {
+  // the four products of one 16-byte group: x gathered from LDS, values decoded when coded
+  auto products = [&](const VWord &w, const uint2 &c, T (&pr)[4]) {
+    uint4 v;
     if constexpr (VC)
-      return make_uint4(ds[w & 0xFFu], ds[(w >> 8) & 0xFFu], ds[(w >> 16) & 0xFFu], ds[w >> 24]);
+      v = make_uint4(ds[w & 0xFFu], ds[(w >> 8) & 0xFFu], ds[(w >> 16) & 0xFFu], ds[w >> 24]);
     else
-      return w;
+      v = w;
+    pr[0] = SR::mul(from_bits<T>(xs[c.x & 0xFFFFu]), from_bits<T>(v.x));
+    pr[1] = SR::mul(from_bits<T>(xs[c.x >> 16]), from_bits<T>(v.y));
+    pr[2] = SR::mul(from_bits<T>(xs[c.y & 0xFFFFu]), from_bits<T>(v.z));
+    pr[3] = SR::mul(from_bits<T>(xs[c.y >> 16]), from_bits<T>(v.w));
   };
-  // ---- light entries: products go to P (sequential 16-byte stores in stream-order layout)
+  // Both loops are software-pipelined: the loads of batch i+1 are issued before batch i is
+  // consumed, so a wave always has one batch of loads in flight behind the stores it issues
+  // (stores count in vmcnt on gfx9: without this every batch would wait out the previous
+  // batch's write latency).  Loads are unconditional on clamped indices -- one basic block.
+  // ---- light entries: products go to P at the entry's own stream position (16-byte stores)
+  // (ping-pong register sets A/B instead of a copy at the loop end: a copy would wait for the
+  // loads it copies)
   const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
-  for (int g0 = ch.s / 4 + tid; g0 < le; g0 += TBS * U) {
-    VWord vw[U];
-    uint2 c[U];
-    uint32_t d[U];
+  {
+    constexpr int S = TBS * U;
+    auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U]) {
 #pragma unroll
-    for (int k = 0; k < U; k++) {   // unconditional loads on clamped indices: one basic block
-      const int g = min(g0 + k * TBS, le - 1);
-      vw[k] = tval[g];
-      c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
-      d[k] = p_in_stream_order ? (uint32_t)g * 4u : gdest[g];
-    }
+      for (int k = 0; k < U; k++) {
+        const int g = min(gbase + k * TBS, le - 1);
+        vw[k] = tval[g];
+        c[k] = tcol2[g];
+      }
+    };
+    auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U]) {
 #pragma unroll
-    for (int k = 0; k < U; k++) {
-      const int g = g0 + k * TBS;
-      if (g < le) {
-        const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
-        const uint4 v = values(vw[k]);
-        uint4 p;
-        p.x = to_bits<T>(SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v.x)));
-        p.y = to_bits<T>(SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v.y)));
-        p.z = to_bits<T>(SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v.z)));
-        p.w = to_bits<T>(SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v.w)));
-        *reinterpret_cast<uint4 *>(P + d[k]) = p;
+      for (int k = 0; k < U; k++) {
+        const int g = gbase + k * TBS;
+        if (g < le) {
+          T pr[4];
+          products(vw[k], c[k], pr);
+          reinterpret_cast<uint4 *>(P)[g] = make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+        }
+      }
+    };
+    VWord va[U], vb[U];
+    uint2 ca[U], cb[U];
+    int g0 = ch.s / 4 + tid;
+    if (g0 < le) {
+      load(g0, va, ca);
+      for (;;) {
+        load(g0 + S, vb, cb);
+        consume(g0, va, ca);
+        g0 += S;
+        if (g0 >= le) break;
+        load(g0 + S, va, ca);
+        consume(g0, vb, cb);
+        g0 += S;
+        if (g0 >= le) break;
       }
     }
   }
@@ -461,43 +489,59 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   // builder knows every piece's split in advance (deterministic, no atomics).
   const int hb = max(ch.s, min(ch.e, ch.hs)) / 4, he = ch.e / 4;
   const int lane = tid & 63;
-  // start on the 64-group boundary (relative to the chunk start) the builder assumed
-  for (int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid; g0 < he; g0 += TBS * U) {
-    VWord vw[U];
-    uint2 c[U];
-    uint32_t d[U];
+  {
+    constexpr int S = TBS * U;
+    auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U], uint32_t (&d)[U]) {
 #pragma unroll
-    for (int k = 0; k < U; k++) {
-      const int g = max(hb, min(g0 + k * TBS, he - 1));
-      vw[k] = tval[g];
-      c[k] = reinterpret_cast<const uint2 *>(tcol)[g];
-      d[k] = gdest[g];
-    }
+      for (int k = 0; k < U; k++) {
+        const int g = max(hb, min(gbase + k * TBS, he - 1));
+        vw[k] = tval[g];
+        c[k] = tcol2[g];
+        d[k] = gdest[g];
+      }
+    };
+    auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U], const uint32_t (&d)[U]) {
 #pragma unroll
-    for (int k = 0; k < U; k++) {
-      const int g = g0 + k * TBS;
-      const bool valid = g >= hb && g < he;
-      if (__ballot(valid)) {   // wave-uniform
-        T t = SR::identity();
-        if (valid) {
-          const uint32_t ca = c[k].x & 0xFFFFu, cb = c[k].x >> 16, cc = c[k].y & 0xFFFFu, cd = c[k].y >> 16;
-          const uint4 v = values(vw[k]);
-          t = SR::mul(from_bits<T>((ca & TCOL_IDENTITY) ? ident : xs[ca]), from_bits<T>(v.x));
-          t = SR::add(t, SR::mul(from_bits<T>((cb & TCOL_IDENTITY) ? ident : xs[cb]), from_bits<T>(v.y)));
-          t = SR::add(t, SR::mul(from_bits<T>((cc & TCOL_IDENTITY) ? ident : xs[cc]), from_bits<T>(v.z)));
-          t = SR::add(t, SR::mul(from_bits<T>((cd & TCOL_IDENTITY) ? ident : xs[cd]), from_bits<T>(v.w)));
+      for (int k = 0; k < U; k++) {
+        const int g = gbase + k * TBS;
+        const bool valid = g >= hb && g < he;
+        if (__ballot(valid)) {   // wave-uniform
+          T t = SR::identity();
+          if (valid) {
+            T pr[4];
+            products(vw[k], c[k], pr);
+            t = SR::add(SR::add(SR::add(pr[0], pr[1]), pr[2]), pr[3]);
+          }
+          const uint32_t key = valid ? d[k] : (0x80000000u | (uint32_t)lane);   // invalid lanes never merge
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const T up = from_bits<T>(__shfl_up(to_bits<T>(t), o, 64));
+            const uint32_t kk = __shfl_up(key, o, 64);
+            if (lane >= o && kk == key)
+              t = SR::add(t, up);
+          }
+          const uint32_t knext = __shfl_down(key, 1, 64);
+          if (valid && (lane == 63 || knext != key))
+            partial[d[k]] = to_bits<T>(t);
         }
-        const uint32_t key = valid ? d[k] : (0x80000000u | (uint32_t)lane);   // invalid lanes never merge
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const T up = from_bits<T>(__shfl_up(to_bits<T>(t), o, 64));
-          const uint32_t kk = __shfl_up(key, o, 64);
-          if (lane >= o && kk == key)
-            t = SR::add(t, up);
-        }
-        const uint32_t knext = __shfl_down(key, 1, 64);
-        if (valid && (lane == 63 || knext != key))
-          partial[d[k]] = to_bits<T>(t);
+      }
+    };
+    VWord va[U], vb[U];
+    uint2 ca[U], cb[U];
+    uint32_t da[U], db[U];
+    // start on the 64-group boundary (relative to the chunk start) the builder assumed
+    int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid;
+    if (g0 < he) {
+      load(g0, va, ca, da);
+      for (;;) {
+        load(g0 + S, vb, cb, db);
+        consume(g0, va, ca, da);
+        g0 += S;
+        if (g0 >= he) break;
+        load(g0 + S, va, ca, da);
+        consume(g0, vb, cb, db);
+        g0 += S;
+        if (g0 >= he) break;
       }
     }
   }

@@ -266,7 +266,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
   int64_t per_tile = 8;
   if (const char *e = getenv("SH_HEAVY_PER_TILE")) per_tile = std::max(1, atoi(e));   // tuning knob
-  const int64_t heavy_thr = std::min<int64_t>(TBIN, std::max<int64_t>(512, per_tile * CT));
+  // (capped at TBIN/4 so that a single light row fits a bin even when every entry is padded to 4)
+  const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
   auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
 
@@ -284,15 +285,10 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   auto light_off = [&](int64_t r) { return (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu); };
   // Bins are filled up to TBIN products.  (Sizing them so that every CU gets the same number of
   // bins was tried for shard-sized matrices: the smaller (bin, tile) pieces cost more than the
-  // ragged last round saves -- 0.115 vs 0.105 ms on a 1/8 shard.  SH_BALANCED_BINS=1 re-enables it.)
+  // ragged last round saves -- 0.115 vs 0.105 ms on a 1/8 shard.)
   // every (bin, tile) piece is padded to 4: leave room so that a padded bin never exceeds TBIN
   // (phase 2 prefetches exactly TBIN products per bin into registers)
-  int64_t bin_target = std::max<int64_t>(TBIN / 2, (int64_t)TBIN - 3ll * CT);
-  if (getenv("SH_BALANCED_BINS") && getenv("SH_BALANCED_BINS")[0] == '1') {
-    const int64_t total_light = light_off(rows);
-    const int64_t rounds = std::max<int64_t>(1, (total_light + (int64_t)TBIN * n_cus - 1) / ((int64_t)TBIN * n_cus));
-    bin_target = std::min<int64_t>(TBIN, std::max<int64_t>(4096, (total_light + rounds * n_cus - 1) / (rounds * n_cus)));
-  }
+  int64_t bin_target = std::max<int64_t>(TBIN / 4, (int64_t)TBIN - 3ll * CT);   // cnt + 3*min(CT,cnt) <= TBIN
   for (int64_t r = 0; r < rows;) {
     int64_t r1 = r + 1;
     while (r1 < rows && r1 - r < TBIN_ROWS && light_off(r1 + 1) - light_off(r) <= bin_target)
@@ -335,6 +331,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       count[t] = 0;
     }
     b.n = (int32_t)n;
+    if (n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
     if (p_off + n > INT32_MAX) return false;
     b.pstart = (int32_t)p_off;
     p_off += n;
@@ -799,9 +796,15 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
-                       e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, A->d_pslot,
-                       A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+    static const bool classic_p2 = [] { const char *v = getenv("SH_P2"); return v && !strcmp(v, "classic"); }();
+    if (classic_p2)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
+                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
+                         A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
+                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
+                         A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());
     if (A->n_tlong > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,

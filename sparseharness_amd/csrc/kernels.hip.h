@@ -98,18 +98,19 @@ template <int NT, int NNZ_CAP> struct ReduceScratch {
   uint16_t lst8[NNZ_CAP / (RL_SHORT + 1) + 1];
   uint16_t lst64[NNZ_CAP / (RL_MID + 1) + 1];
   uint16_t lstB[NNZ_CAP / (RL_WAVE + 1) + 1];
-  int32_t cnt[4];
+  int32_t cnt[8];   // two sets of {n8, n64, nB, -}: the wave-specialised phase 2 alternates them
   uint32_t wred[NT / 64];
 };
 
+// `tid` in [0, NT) numbers the threads that take part (all of them hit the barriers inside);
+// `cnt` are the three list counters, zeroed before the barrier that published prod[].
 template <class SR, int NT, int NNZ_CAP>
 __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t *rp, int nr, int r0,
-                                            ReduceScratch<NT, NNZ_CAP> &sc, const uint32_t *__restrict__ y,
+                                            ReduceScratch<NT, NNZ_CAP> &sc, int32_t *cnt, const int tid,
+                                            const uint32_t *__restrict__ y,
                                             typename SR::T alpha, typename SR::T beta, bool use_y,
                                             uint32_t *__restrict__ out, const StepDev &st) {
   using T = typename SR::T;
-  const int tid = threadIdx.x;
-  // sc.cnt[] was zeroed before the barrier that published prod[]
   for (int row = tid; row < nr; row += NT) {
     const int s = rp[row] & RP_MASK, len = (rp[row + 1] & RP_MASK) - s;
     if (rp[row] & RP_SKIP)
@@ -120,15 +121,15 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
         acc = SR::add(acc, from_bits<T>(prod[s + j]));
       finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
     } else if (len <= RL_MID) {
-      sc.lst8[atomicAdd(&sc.cnt[0], 1)] = (uint16_t)row;
+      sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
     } else if (len <= RL_WAVE) {
-      sc.lst64[atomicAdd(&sc.cnt[1], 1)] = (uint16_t)row;
+      sc.lst64[atomicAdd(&cnt[1], 1)] = (uint16_t)row;
     } else {
-      sc.lstB[atomicAdd(&sc.cnt[2], 1)] = (uint16_t)row;
+      sc.lstB[atomicAdd(&cnt[2], 1)] = (uint16_t)row;
     }
   }
   lds_barrier();
-  const int n8 = sc.cnt[0], n64 = sc.cnt[1], nB = sc.cnt[2];
+  const int n8 = cnt[0], n64 = cnt[1], nB = cnt[2];
   for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
     const int row = sc.lst8[idx], l = tid & 7;
     const int e = rp[row + 1] & RP_MASK;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(BS) void spmv_csr_kernel(
     for (int i = tid; i <= nr; i += BS)
       rp[i] -= base;
     __syncthreads();
-    reduce_rows_from_lds<SR, BS, NNZ_BLK>(prod, rp, nr, r0, sc, y, alpha, beta, use_y, out, st);
+    reduce_rows_from_lds<SR, BS, NNZ_BLK>(prod, rp, nr, r0, sc, sc.cnt, tid, y, alpha, beta, use_y, out, st);
   } else {
     // ------------------------------------------------------- long-row segment
     const LongSeg sg = segs[b - n_stream];
@@ -554,61 +555,73 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
 // one of them sits between its barriers.
 constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers T2BS*P2U*4 = 32768 products)
 
+// The prefetch of phase 2 goes through inline-asm loads.  hipcc tracks vmcnt only for loads it
+// emitted itself and is conservative across the loop back-edge: with compiler-visible loads it
+// drained the whole prefetch in front of the reduction, waited between the refills, and the P
+// addresses of the next bin depended on a gsrc load issued in the same iteration (~2 us per bin
+// with nothing else in flight).  With asm loads the compiler inserts no waits for them at all;
+// the single hand-placed wait is phase2_wait_all() at the top of the loop, whose operand list
+// ties every prefetch register to it so that no use can be scheduled above it.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void async_load(v4u32 &dst, const void *addr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void async_load(v2u32 &dst, const void *addr) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+
 template <class SR>
 __global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
     const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
-    const uint32_t *__restrict__ P, const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
-    const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
-    uint32_t *__restrict__ out, StepDev st) {
+    const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
+    const uint32_t *__restrict__ gsrc, const uint32_t *__restrict__ y, typename SR::T alpha,
+    typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
 
   __shared__ uint32_t prod[TBIN];
   __shared__ int32_t rp[TBIN_ROWS + 1];
   __shared__ ReduceScratch<T2BS, TBIN> sc;
   const int tid = threadIdx.x;
   const bool use_y = use_y_i != 0;
-  const uint4 *P4 = reinterpret_cast<const uint4 *>(P);
-
-  uint4 p[P2U];
-  uint2 s[P2U];
+  const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
+  static_assert(P2U == 8, "phase2_wait_all lists the prefetch registers explicitly");
   constexpr int RPU = TBIN_ROWS / T2BS + 1;   // row_ptr entries a thread prefetches
-  int32_t rpn[RPU];
-  // All prefetch loads are issued unconditionally on clamped indices so that they sit in one
-  // basic block and fly together (a per-load `if` makes hipcc wait after each one); the
-  // predicate is applied when the registers are consumed.
-  auto fetch = [&](const RowBin &bn) {
+  static_assert(RPU == 5, "phase2_wait_all lists the prefetch registers explicitly");
+
+  v4u32 p[P2U];        // products of the bin about to be scattered ...
+  v2u32 s[P2U];        // ... and their slots
+  uint32_t gs[P2U];    // gsrc of the bin after it (the P addresses of the next prefetch)
+  uint32_t rpr[RPU];   // raw light row offsets of the bin about to be scattered
+  // All prefetch loads are unconditional on clamped indices; the predicate is applied when the
+  // registers are consumed.
+  auto load_rp = [&](const RowBin &bn) {
 #pragma unroll
-    for (int k = 0; k < RPU; k++) {   // light row offsets; bit 31 = heavy row (skipped here)
-      const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * T2BS, bn.nr)];
-      rpn[k] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)bn.csr0) | ((v >> 31) ? RP_SKIP : 0);
-    }
-    const int n4 = bn.n / 4;
-    if (n4 == 0)
-      return;
-    // bin-major P (gsrc == nullptr): the bin's products are one contiguous run; stream-order P:
-    // gsrc gives, per group of 4, where phase 1 left them (one piece per column tile).
-    const uint2 *S4 = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
-    uint32_t src[P2U];
-    if (gsrc) {
-      const uint32_t *G4 = gsrc + bn.pstart / 4;
-#pragma unroll
-      for (int k = 0; k < P2U; k++)
-        src[k] = G4[min(tid + k * T2BS, n4 - 1)];
-#pragma unroll
-      for (int k = 0; k < P2U; k++)
-        src[k] >>= 2;
-    } else {
-#pragma unroll
-      for (int k = 0; k < P2U; k++)
-        src[k] = (uint32_t)(bn.pstart / 4 + min(tid + k * T2BS, n4 - 1));
-    }
-#pragma unroll
-    for (int k = 0; k < P2U; k++)
-      s[k] = S4[min(tid + k * T2BS, n4 - 1)];
-#pragma unroll
-    for (int k = 0; k < P2U; k++)
-      p[k] = P4[src[k]];
+    for (int k = 0; k < RPU; k++)
+      async_load(rpr[k], row_ptr + bn.r0 + min(tid + k * T2BS, bn.nr));
   };
-  auto put = [&](uint2 sl, uint4 pr) {
+  auto load_gs = [&](const RowBin &bn) {
+    const int n4 = max(bn.n / 4, 1);
+    const uint32_t *G4 = gsrc + bn.pstart / 4;
+#pragma unroll
+    for (int k = 0; k < P2U; k++)
+      async_load(gs[k], G4 + min(tid + k * T2BS, n4 - 1));
+  };
+  auto wait_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                   "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])
+                 :
+                 : "memory");
+    asm volatile(""
+                 : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]), "+v"(gs[7]),
+                   "+v"(rpr[0]), "+v"(rpr[1]), "+v"(rpr[2]), "+v"(rpr[3]), "+v"(rpr[4])
+                 :
+                 : "memory");
+  };
+  auto put = [&](v2u32 sl, v4u32 pr) {
     const uint32_t sa = sl.x & 0xFFFFu, sb = sl.x >> 16, sc_ = sl.y & 0xFFFFu, sd = sl.y >> 16;
     if (sa != TSLOT_PAD) prod[sa] = pr.x;
     if (sb != TSLOT_PAD) prod[sb] = pr.y;
@@ -628,64 +641,228 @@ __global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
 #endif
   if (b >= n_bins)
     return;
-  RowBin bn = bins[b];
-  fetch(bn);
-  for (; b < n_bins; b += gridDim.x) {
-    const int n4 = bn.n / 4;
-    const RowBin cur = bn;
-    const bool has_next = b + (int)gridDim.x < n_bins;
-    if (has_next)
-      bn = bins[b + gridDim.x];
+  // (descriptors of bins that do not exist are read from the last bin instead: clamped scalar
+  // loads; a select against a dummy made hipcc use FLAT vector loads, whose wait drained the prefetch)
+  RowBin cur = bins[b];
+  RowBin nxt = bins[min(b + G, n_bins - 1)];
+  // prologue: the first bin's stream (its gsrc is an ordinary dependent load), then gsrc of the second
+  {
+    const int n4 = max(cur.n / 4, 1);
+    const uint32_t *G4 = gsrc + cur.pstart / 4;
+    const v2u32 *S4 = reinterpret_cast<const v2u32 *>(pslot + cur.pstart);
+    uint32_t src[P2U];
+#pragma unroll
+    for (int k = 0; k < P2U; k++)
+      src[k] = G4[min(tid + k * T2BS, n4 - 1)];
+#pragma unroll
+    for (int k = 0; k < P2U; k++) {
+      async_load(s[k], S4 + min(tid + k * T2BS, n4 - 1));
+      async_load(p[k], P4 + min((int32_t)(src[k] >> 2), last_group));
+    }
+    load_rp(cur);
+    load_gs(nxt);
+  }
+  for (; b < n_bins; b += G) {
+    const int n4 = cur.n / 4;
+    const bool has_next = b + G < n_bins;
+    const RowBin nxt2 = bins[min(b + 2 * G, n_bins - 1)];
+    wait_all();   // p/s/rpr of `cur` and gs of `nxt` are in registers now
     // (the previous iteration ended with a barrier: prod/rp/sc are free)
     if (tid < 4)
       sc.cnt[tid] = 0;
 #pragma unroll
     for (int k = 0; k < RPU; k++)
-      if (tid + k * T2BS <= cur.nr)
-        rp[tid + k * T2BS] = rpn[k];
+      if (tid + k * T2BS <= cur.nr) {   // light row offsets; bit 31 = heavy row (skipped by the reduction)
+        const uint32_t v = rpr[k];
+        rp[tid + k * T2BS] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)cur.csr0) | ((v >> 31) ? RP_SKIP : 0);
+      }
     // Scatter the current bin out of the registers and refill each register pair with the NEXT
     // bin's group as soon as it is free: the next bin's whole stream is in flight before this
-    // bin's reduction starts.  (gsrc of the next bin is fetched first: P addresses depend on it.)
-    const int nn4 = has_next ? bn.n / 4 : 0;
-    const uint2 *S4n = reinterpret_cast<const uint2 *>(pslot + bn.pstart);
-    uint32_t srcn[P2U];
-    if (nn4 > 0) {
-      if (gsrc) {
-        const uint32_t *G4 = gsrc + bn.pstart / 4;
-#pragma unroll
-        for (int k = 0; k < P2U; k++)
-          srcn[k] = G4[min(tid + k * T2BS, nn4 - 1)];
-      } else {
-#pragma unroll
-        for (int k = 0; k < P2U; k++)
-          srcn[k] = (uint32_t)(bn.pstart + 4 * min(tid + k * T2BS, nn4 - 1));
-      }
-    }
-    if (has_next) {
-#pragma unroll
-      for (int k = 0; k < RPU; k++) {
-        const uint32_t v = (uint32_t)row_ptr[bn.r0 + min(tid + k * T2BS, bn.nr)];
-        rpn[k] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)bn.csr0) | ((v >> 31) ? RP_SKIP : 0);
-      }
-    }
+    // bin's reduction starts, and gsrc of the bin after that right behind it.
+    const int nn4 = max(nxt.n / 4, 1);   // (no next bin: harmless re-read of the last bin's stream)
+    const v2u32 *S4n = reinterpret_cast<const v2u32 *>(pslot + nxt.pstart);
 #pragma unroll
     for (int k = 0; k < P2U; k++) {
       if (tid + k * T2BS < n4)
         put(s[k], p[k]);
-      if (nn4 > 0) {   // workgroup-uniform
-        s[k] = S4n[min(tid + k * T2BS, nn4 - 1)];
-        p[k] = P4[srcn[k] >> 2];
+      async_load(s[k], S4n + min(tid + k * T2BS, nn4 - 1));
+      async_load(p[k], P4 + min((int32_t)(gs[k] >> 2), last_group));   // clamp: a stale register must not fault
+    }
+    load_rp(nxt);
+    load_gs(nxt2);
+    lds_barrier();
+    reduce_rows_from_lds<SR, T2BS, TBIN>(prod, rp, cur.nr, cur.r0, sc, sc.cnt, tid, y, alpha, beta, use_y, out, st);
+    lds_barrier();
+    cur = nxt;
+    nxt = nxt2;
+    (void)has_next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch must land before the wave ends
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 2, wave-specialised (default).  One 1024-thread workgroup per CU; waves 0-3 are LOADERS,
+// waves 4-15 REDUCERS, and the LDS holds two product images:
+//   loaders   stream bin j+1 (P pieces via gsrc, slots) and scatter it into image (j+1)&1;
+//   reducers  reduce bin j out of image j&1 and write the rows.
+// Why: a CU sustains only what its miss queue holds per memory latency, so HBM time is lost
+// whenever no wave of the CU has a load to issue.  With every wave alternating between "stream
+// a bin" and "reduce a bin" (spmv_tiled_phase2 above, two workgroups per CU) the two workgroups
+// fall into step and the CU's load queue runs dry during the reductions: 277 us where the loads
+// alone take 200 us.  Here four waves do nothing but keep loads in flight -- a rolling window of
+// two quarter-bin steps per thread, hand-scheduled: asm loads, one s_waitcnt vmcnt(8) per step --
+// and the reduction runs beside them on the other twelve.
+// Per-thread order of VMEM issue in the loaders (in-order return makes the wait a constant):
+//   step q:  wait vmcnt(8)  -> P/S(q) and gsrc(q+2) have landed, P/S(q+1) (8 loads) still fly
+//            scatter P/S(q) into the image; issue gsrc(q+3) (4 loads); issue P/S(q+2) (8 loads)
+// Barriers (s_barrier is workgroup-wide, so both roles execute the same two per bin): MID is the
+// one inside the reduction (list hand-over), END swaps the images.
+#ifndef SH_P2S_LD
+#define SH_P2S_LD 256
+#endif
+constexpr int P2S_BS = 1024, P2S_LD = SH_P2S_LD, P2S_RD = P2S_BS - P2S_LD;   // threads: all, loaders, reducers
+constexpr int P2S_K = 4;                       // groups (of 4 products) per loader thread per step
+constexpr int P2S_Q = P2S_K * P2S_LD;          // groups per step: 1024 (a quarter bin) with 256 loaders
+constexpr int P2S_NS = TBIN / 4 / P2S_Q;       // steps per bin: 4
+constexpr int P2S_RPU = (TBIN_ROWS + P2S_RD) / P2S_RD;   // row_ptr entries per reducer thread: 3
+static_assert(P2S_NS * P2S_Q * 4 == TBIN && P2S_NS % 2 == 0 && TBIN_ROWS + 1 <= P2S_RPU * P2S_RD, "phase-2 geometry");
+
+template <class SR>
+__global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
+    const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
+    const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
+    const uint32_t *__restrict__ gsrc, const uint32_t *__restrict__ y, typename SR::T alpha,
+    typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
+  __shared__ uint32_t prod[2][TBIN];
+  __shared__ int32_t rp[2][TBIN_ROWS + 1];
+  __shared__ ReduceScratch<P2S_RD, TBIN> sc;
+  const int tid = threadIdx.x;
+  const bool use_y = use_y_i != 0;
+  const int G = gridDim.x;
+  // consecutive bins on one XCD (see spmv_tiled_phase2)
+  const int b0 = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  if (b0 >= n_bins)
+    return;
+  const int nb = (n_bins - b0 + G - 1) / G;    // bins of this workgroup: b0, b0+G, ...
+  auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * G]; };   // clamped: scalar loads
+  if (tid < 8)
+    sc.cnt[tid] = 0;
+  lds_barrier();
+
+  if (tid < P2S_LD) {
+    // ------------------------------------------------------------------ loaders
+    const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
+    // addresses of step q = 4*j + quarter
+    auto issue_gs = [&](const RowBin &bn, int quarter, uint32_t (&g)[P2S_K]) {
+      const int n4 = max(bn.n / 4, 1);
+      const uint32_t *G4 = gsrc + bn.pstart / 4;
+#pragma unroll
+      for (int k = 0; k < P2S_K; k++)
+        async_load(g[k], G4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
+    };
+    auto issue_ps = [&](const RowBin &bn, int quarter, const uint32_t (&g)[P2S_K], v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K]) {
+      const int n4 = max(bn.n / 4, 1);
+      const v2u32 *S4 = reinterpret_cast<const v2u32 *>(pslot + bn.pstart);
+#pragma unroll
+      for (int k = 0; k < P2S_K; k++) {
+        async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
+        async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));   // clamp: a stale register must not fault
       }
+    };
+    auto wait8 = [&](v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K], uint32_t (&g)[P2S_K]) {
+      asm volatile("s_waitcnt vmcnt(8)"
+                   : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]),
+                     "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])
+                   :
+                   : "memory");
+    };
+    auto scatter = [&](uint32_t *img, const RowBin &bn, int quarter, const v4u32 (&p)[P2S_K], const v2u32 (&s)[P2S_K]) {
+      const int n4 = bn.n / 4;
+#pragma unroll
+      for (int k = 0; k < P2S_K; k++)
+        if (quarter * P2S_Q + k * P2S_LD + tid < n4) {
+          const uint32_t s0 = s[k].x & 0xFFFFu, s1 = s[k].x >> 16, s2 = s[k].y & 0xFFFFu, s3 = s[k].y >> 16;
+          if (s0 != TSLOT_PAD) img[s0] = p[k].x;
+          if (s1 != TSLOT_PAD) img[s1] = p[k].y;
+          if (s2 != TSLOT_PAD) img[s2] = p[k].z;
+          if (s3 != TSLOT_PAD) img[s3] = p[k].w;
+        }
+    };
+    RowBin cur = bin_at(0), nxt = bin_at(1), nxt2 = bin_at(2);
+    // step q + d (d = 2, 3) seen from step s of the current bin: which bin, which step in it
+    auto bin_of = [&](int s_plus_d) -> const RowBin & {
+      return s_plus_d < P2S_NS ? cur : (s_plus_d < 2 * P2S_NS ? nxt : nxt2);
+    };
+    v4u32 p[2][P2S_K];
+    v2u32 sl[2][P2S_K];
+    uint32_t g[2][P2S_K];
+    // prologue: gsrc(0), gsrc(1) by ordinary loads; then P/S(0), gsrc(2), P/S(1) in steady-state order
+    {
+#pragma unroll
+      for (int k = 0; k < P2S_K; k++) {
+        const RowBin &b1 = bin_of(1);
+        g[0][k] = (gsrc + cur.pstart / 4)[min(0 * P2S_Q + k * P2S_LD + tid, max(cur.n / 4, 1) - 1)];
+        g[1][k] = (gsrc + b1.pstart / 4)[min((1 % P2S_NS) * P2S_Q + k * P2S_LD + tid, max(b1.n / 4, 1) - 1)];
+      }
+      issue_ps(cur, 0, g[0], p[0], sl[0]);
+      issue_gs(bin_of(2), 2 % P2S_NS, g[0]);
+      issue_ps(bin_of(1), 1 % P2S_NS, g[1], p[1], sl[1]);
     }
-    // bins are sized so that padding never pushes them past T2BS*P2U groups (engine.hip); this
-    // loop only runs for plans built with other limits
-    for (int g = tid + P2U * T2BS; g < n4; g += T2BS) {
-      const uint32_t src = gsrc ? gsrc[cur.pstart / 4 + g] / 4 : (uint32_t)(cur.pstart / 4 + g);
-      put(reinterpret_cast<const uint2 *>(pslot + cur.pstart)[g], P4[src]);
+    for (int j = 0; j <= nb; j++) {
+      if (j < nb) {
+        uint32_t *img = prod[j & 1];
+#pragma unroll
+        for (int s = 0; s < P2S_NS; s++) {
+          constexpr int dummy = 0; (void)dummy;
+          const int a = s & 1;
+          wait8(p[a], sl[a], g[a]);                        // P/S(q) and gsrc(q+2) have landed
+          scatter(img, cur, s, p[a], sl[a]);
+          issue_gs(bin_of(s + 3), (s + 3) % P2S_NS, g[a ^ 1]);        // gsrc(q+3)
+          issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
+          if (s == P2S_NS / 2 - 1)
+            lds_barrier();   // MID
+        }
+        cur = nxt;
+        nxt = nxt2;
+        nxt2 = bin_at(j + 3);
+      } else {
+        lds_barrier();   // MID of the last reduction
+      }
+      lds_barrier();     // END
     }
-    lds_barrier();
-    reduce_rows_from_lds<SR, T2BS, TBIN>(prod, rp, cur.nr, cur.r0, sc, y, alpha, beta, use_y, out, st);
-    lds_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave ends
+  } else {
+    // ------------------------------------------------------------------ reducers
+    const int rt = tid - P2S_LD;
+    RowBin prev = bin_at(0);
+    for (int j = 0; j <= nb; j++) {
+      const RowBin cur = bin_at(j);
+      // row offsets of the bin being streamed now (needed by the next reduction)
+      uint32_t rr[P2S_RPU];
+      if (j < nb) {
+#pragma unroll
+        for (int k = 0; k < P2S_RPU; k++)
+          rr[k] = (uint32_t)row_ptr[cur.r0 + min(rt + k * P2S_RD, cur.nr)];
+      }
+      int32_t *cnt = sc.cnt + 4 * (j & 1);
+      if (j >= 1)
+        reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
+                                               alpha, beta, use_y, out, st);   // contains MID
+      else
+        lds_barrier();   // MID
+      if (rt < 4)
+        sc.cnt[4 * ((j + 1) & 1) + rt] = 0;   // the other set: last read before the previous END
+      if (j < nb) {
+#pragma unroll
+        for (int k = 0; k < P2S_RPU; k++)
+          if (rt + k * P2S_RD <= cur.nr) {   // light row offsets; bit 31 = heavy row (skipped by the reduction)
+            const uint32_t v = rr[k];
+            rp[j & 1][rt + k * P2S_RD] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)cur.csr0) | ((v >> 31) ? RP_SKIP : 0);
+          }
+      }
+      lds_barrier();     // END
+      prev = cur;
+    }
   }
 }
 

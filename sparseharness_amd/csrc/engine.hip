@@ -26,6 +26,9 @@ struct sh_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // side stream for the heavy-row fixup of the tiled plan (runs beside phase 2; both only need phase 1)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t *d_flags = nullptr;   // per-iteration convergence flags
   int32_t n_flags = 0;
   int32_t *h_flag = nullptr;    // pinned
@@ -136,6 +139,9 @@ static int engine_create(int device, void *stream, bool borrow, sh_engine **out)
   }
   if (r == hipSuccess) r = hipEventCreate(&e->ev0);
   if (r == hipSuccess) r = hipEventCreate(&e->ev1);
+  if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking);
+  if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+  if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   if (r == hipSuccess) r = hipHostMalloc((void **)&e->h_flag, 64, hipHostMallocDefault);
   hipDeviceProp_t prop;
   if (r == hipSuccess) r = hipGetDeviceProperties(&prop, device);
@@ -166,6 +172,9 @@ int sh_engine_destroy(sh_engine *e) {
   if (e->h_flag) (void)hipHostFree(e->h_flag);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return SH_OK;
@@ -796,6 +805,18 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
+    // heavy rows only need phase 1's partials and write rows phase 2 never touches: fork them
+    // onto the side stream so that their 14 us hide under phase 2 (SH_FIXUP_INLINE=1: same stream)
+    static const bool fixup_inline = [] { const char *v = getenv("SH_FIXUP_INLINE"); return v && v[0] == '1'; }();
+    const bool fork = A->n_tlong > 0 && !fixup_inline;
+    if (fork) {
+      HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+      HIP_TRY(e, hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->aux, A->d_tlong,
+                         A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+      HIP_TRY(e, hipGetLastError());
+      HIP_TRY(e, hipEventRecord(e->ev_join, e->aux));
+    }
     static const bool classic_p2 = [] { const char *v = getenv("SH_P2"); return v && !strcmp(v, "classic"); }();
     if (classic_p2)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
@@ -806,7 +827,9 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
                          A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());
-    if (A->n_tlong > 0) {
+    if (fork) {
+      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    } else if (A->n_tlong > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,
                          A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());

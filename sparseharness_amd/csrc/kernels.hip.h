@@ -89,7 +89,10 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
 //   longer       the whole workgroup (stride-NT sums, wave trees, then waves in order)
 // Rows are classified by one pass that finishes the short ones on the spot
 // and appends the others to three LDS work lists.
-constexpr int RL_SHORT = 24, RL_MID = 256, RL_WAVE = 4096;
+#ifndef SH_RL_SHORT
+#define SH_RL_SHORT 24
+#endif
+constexpr int RL_SHORT = SH_RL_SHORT, RL_MID = 256, RL_WAVE = 4096;
 // rp[] entries may carry RP_SKIP: the row is produced elsewhere (heavy rows of the tiled plan)
 // and must be neither written nor tested here.  Offsets stay below 2^30.
 constexpr int32_t RP_SKIP = 1 << 30, RP_MASK = RP_SKIP - 1;

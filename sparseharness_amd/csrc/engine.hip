@@ -805,10 +805,20 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
-    // heavy rows only need phase 1's partials and write rows phase 2 never touches: fork them
-    // onto the side stream so that their 14 us hide under phase 2 (SH_FIXUP_INLINE=1: same stream)
-    static const bool fixup_inline = [] { const char *v = getenv("SH_FIXUP_INLINE"); return v && v[0] == '1'; }();
-    const bool fork = A->n_tlong > 0 && !fixup_inline;
+    static const bool classic_p2 = [] { const char *v = getenv("SH_P2"); return v && !strcmp(v, "classic"); }();
+    if (!classic_p2 && A->n_bins > 0) {
+      // wave-specialised phase 2; its reducer waves also add up the heavy rows' partials while
+      // the loaders fill the first image, so one SpMV is two launches
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
+                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
+                         A->d_gsrc, A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
+                         (uint32_t *)out->d, st);
+      HIP_TRY(e, hipGetLastError());
+      return SH_OK;
+    }
+    // classic phase 2 (SH_P2=classic, or no light bins at all).  Heavy rows only need phase 1's
+    // partials and write rows phase 2 never touches: fork them onto the side stream.
+    const bool fork = A->n_tlong > 0 && A->n_bins > 0;
     if (fork) {
       HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
       HIP_TRY(e, hipStreamWaitEvent(e->aux, e->ev_fork, 0));
@@ -817,16 +827,12 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       HIP_TRY(e, hipGetLastError());
       HIP_TRY(e, hipEventRecord(e->ev_join, e->aux));
     }
-    static const bool classic_p2 = [] { const char *v = getenv("SH_P2"); return v && !strcmp(v, "classic"); }();
-    if (classic_p2)
+    if (A->n_bins > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
                          e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
                          A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
-                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
-                         A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
-    HIP_TRY(e, hipGetLastError());
+      HIP_TRY(e, hipGetLastError());
+    }
     if (fork) {
       HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
     } else if (A->n_tlong > 0) {

@@ -329,6 +329,54 @@ __global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
   }
 }
 
+// The same sum by ONE wave (bit-identical: lane l plays threads l, l+64, l+128, l+192 of the block
+// above).  Used by the wave-specialised phase 2, whose reducer waves are idle while the loaders
+// fill the first bin.
+template <class SR>
+__device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__restrict__ partial, int lane,
+                                         const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
+                                         bool use_y, uint32_t *__restrict__ out, const StepDev &st) {
+  using T = typename SR::T;
+  T acc[HFIX_BS / 64];
+#pragma unroll
+  for (int w = 0; w < HFIX_BS / 64; w++)
+    acc[w] = SR::identity();
+  constexpr int HU = 4;   // chunks of HFIX_BS partials in flight per lane (a row can have thousands)
+  const uint32_t ident = to_bits<T>(SR::identity());
+  for (int k0 = 0; k0 < lr.nslots; k0 += HFIX_BS * HU) {
+    uint32_t v[HU][HFIX_BS / 64];
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+#pragma unroll
+      for (int w = 0; w < HFIX_BS / 64; w++) {
+        const int k = k0 + u * HFIX_BS + w * 64 + lane;
+        v[u][w] = partial[lr.slot0 + min(k, lr.nslots - 1)];   // clamped: branch-free, all loads fly together
+      }
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+#pragma unroll
+      for (int w = 0; w < HFIX_BS / 64; w++) {
+        const int k = k0 + u * HFIX_BS + w * 64 + lane;
+        if (k < lr.nslots)
+          acc[w] = SR::add(acc[w], from_bits<T>(v[u][w]));
+      }
+  }
+  (void)ident;
+#pragma unroll
+  for (int w = 0; w < HFIX_BS / 64; w++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      acc[w] = SR::add(acc[w], from_bits<T>(__shfl_xor(to_bits<T>(acc[w]), o, 64)));
+  }
+  if (lane == 0) {
+    T t = acc[0];
+#pragma unroll
+    for (int w = 1; w < HFIX_BS / 64; w++)
+      t = SR::add(t, acc[w]);
+    finish_row<SR>(lr.row, t, y, alpha, beta, use_y, out, st);
+  }
+}
+
 // ===========================================================================
 // x-tiled two-phase plan (for matrices whose x does not fit the per-XCD L2).
 //
@@ -719,7 +767,9 @@ __global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
 //   step q:  wait vmcnt(8)  -> P/S(q) and gsrc(q+2) have landed, P/S(q+1) (8 loads) still fly
 //            scatter P/S(q) into the image; issue gsrc(q+3) (4 loads); issue P/S(q+2) (8 loads)
 // Barriers (s_barrier is workgroup-wide, so both roles execute the same two per bin): MID is the
-// one inside the reduction (list hand-over), END swaps the images.
+// one inside the reduction (list hand-over), END swaps the images.  While the loaders fill the
+// very first image the reducers have nothing to reduce: they add up the heavy rows' partials
+// (the job of spmv_heavy_fixup, same summation order) instead of idling.
 #ifndef SH_P2S_LD
 #define SH_P2S_LD 256
 #endif
@@ -734,7 +784,8 @@ template <class SR>
 __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
     const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
     const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
-    const uint32_t *__restrict__ gsrc, const uint32_t *__restrict__ y, typename SR::T alpha,
+    const uint32_t *__restrict__ gsrc, const LongRow *__restrict__ heavy_rows, int32_t n_heavy,
+    const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
     typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   __shared__ uint32_t prod[2][TBIN];
   __shared__ int32_t rp[2][TBIN_ROWS + 1];
@@ -851,8 +902,13 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
       if (j >= 1)
         reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
                                                alpha, beta, use_y, out, st);   // contains MID
-      else
+      else {
+        // nothing to reduce yet (the loaders are filling the first image): add up the heavy rows'
+        // phase-1 partials meanwhile, one row per wave
+        for (int h = (int)blockIdx.x * (P2S_RD / 64) + (rt >> 6); h < n_heavy; h += G * (P2S_RD / 64))
+          heavy_row_by_wave<SR>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
         lds_barrier();   // MID
+      }
       if (rt < 4)
         sc.cnt[4 * ((j + 1) & 1) + rt] = 0;   // the other set: last read before the previous END
       if (j < nb) {

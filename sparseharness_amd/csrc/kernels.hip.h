@@ -112,8 +112,18 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
                                             ReduceScratch<NT, NNZ_CAP> &sc, int32_t *cnt, const int tid,
                                             const uint32_t *__restrict__ y,
                                             typename SR::T alpha, typename SR::T beta, bool use_y,
-                                            uint32_t *__restrict__ out, const StepDev &st) {
+                                            uint32_t *__restrict__ out, const StepDev &st,
+                                            uint32_t *stage = nullptr) {
   using T = typename SR::T;
+  // stage != nullptr (workgroup-uniform): the row's dot goes to stage[row] in LDS and the caller
+  // applies the epilogue later in a coalesced pass (used when the epilogue reads y / prev: those
+  // loads would otherwise sit, one row at a time, in the middle of the reduction)
+  auto emit = [&](int row, T acc) {
+    if (stage)
+      stage[row] = to_bits<T>(acc);
+    else
+      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+  };
   for (int row = tid; row < nr; row += NT) {
     const int s = rp[row] & RP_MASK, len = (rp[row + 1] & RP_MASK) - s;
     if (rp[row] & RP_SKIP)
@@ -122,7 +132,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       T acc = SR::identity();
       for (int j = 0; j < len; j++)
         acc = SR::add(acc, from_bits<T>(prod[s + j]));
-      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+      emit(row, acc);
     } else if (len <= RL_MID) {
       sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
     } else if (len <= RL_WAVE) {
@@ -143,7 +153,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
     for (int o = 4; o > 0; o >>= 1)
       acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
     if (l == 0)
-      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+      emit(row, acc);
   }
   for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
     const int row = sc.lst64[idx], l = tid & 63;
@@ -155,7 +165,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
     for (int o = 32; o > 0; o >>= 1)
       acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
     if (l == 0)
-      finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
+      emit(row, acc);
   }
   for (int idx = 0; idx < nB; idx++) {   // nB is workgroup-uniform
     const int row = sc.lstB[idx];
@@ -173,7 +183,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       T t = from_bits<T>(sc.wred[0]);
       for (int w = 1; w < NT / 64; w++)
         t = SR::add(t, from_bits<T>(sc.wred[w]));
-      finish_row<SR>(r0 + row, t, y, alpha, beta, use_y, out, st);
+      emit(row, t);
     }
     lds_barrier();
   }
@@ -789,9 +799,12 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
     typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   __shared__ uint32_t prod[2][TBIN];
   __shared__ int32_t rp[2][TBIN_ROWS + 1];
+  __shared__ uint32_t dots[TBIN_ROWS];
   __shared__ ReduceScratch<P2S_RD, TBIN> sc;
   const int tid = threadIdx.x;
   const bool use_y = use_y_i != 0;
+  // epilogues that read y or the previous vector run as a coalesced pass after one more barrier (MID2)
+  const bool staged = use_y || st.changed != nullptr;
   const int G = gridDim.x;
   // consecutive bins on one XCD (see spmv_tiled_phase2)
   const int b0 = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
@@ -882,6 +895,8 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
       } else {
         lds_barrier();   // MID of the last reduction
       }
+      if (staged)
+        lds_barrier();   // MID2
       lds_barrier();     // END
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave ends
@@ -899,15 +914,27 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
           rr[k] = (uint32_t)row_ptr[cur.r0 + min(rt + k * P2S_RD, cur.nr)];
       }
       int32_t *cnt = sc.cnt + 4 * (j & 1);
-      if (j >= 1)
+      if (j >= 1) {
         reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
-                                               alpha, beta, use_y, out, st);   // contains MID
-      else {
+                                               alpha, beta, use_y, out, st, staged ? dots : nullptr);   // contains MID
+        if (staged) {
+          lds_barrier();   // MID2
+          const int32_t *rpp = rp[(j - 1) & 1];
+#pragma unroll
+          for (int k = 0; k < P2S_RPU; k++) {
+            const int i = rt + k * P2S_RD;
+            if (i < prev.nr && !(rpp[i] & RP_SKIP))
+              finish_row<SR>(prev.r0 + i, from_bits<typename SR::T>(dots[i]), y, alpha, beta, use_y, out, st);
+          }
+        }
+      } else {
         // nothing to reduce yet (the loaders are filling the first image): add up the heavy rows'
         // phase-1 partials meanwhile, one row per wave
         for (int h = (int)blockIdx.x * (P2S_RD / 64) + (rt >> 6); h < n_heavy; h += G * (P2S_RD / 64))
           heavy_row_by_wave<SR>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
         lds_barrier();   // MID
+        if (staged)
+          lds_barrier(); // MID2
       }
       if (rt < 4)
         sc.cnt[4 * ((j + 1) & 1) + rt] = 0;   // the other set: last read before the previous END

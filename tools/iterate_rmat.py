@@ -24,6 +24,8 @@ with Engine(0) as eng:
         A = eng.upload_csr(n, n, rp, ci, vals)
         x0 = O.initial_vector(sr, n)
         x, y, sc = eng.vector(x0), eng.vector(x0), eng.alloc(n)
+        eng.iterate(sr, A, x, y, sc, a, b, 1e-4, 1)          # warm-up trial (first launch loads the code object),
+        x.upload(x0)                                         # then reset the inputs as the apps do between trials
         t = time.perf_counter()
         iters, conv, per, total = eng.iterate(sr, A, x, y, sc, a, b, 1e-4, 200)
         wall = time.perf_counter() - t
@@ -35,6 +37,7 @@ with Engine(0) as eng:
         bytes_it = A.algorithmic_bytes(reads_y=(sr == O.MIN_PLUS_F32))
         out[name] = {"plan": A.plan()[0], "iterations": iters, "converged": conv, "bit_exact_vs_oracle": bool(ok),
                      "device_ms_total": round(total / 1e6, 3), "device_ms_per_iteration": round(total / 1e6 / iters, 4),
+                     "device_us_each_iteration": [round(p / 1e3, 1) for p in per],
                      "wall_ms_total_incl_flag_readback": round(wall * 1e3, 3),
                      "algorithmic_GBps": round(bytes_it / (total / iters), 1), "cpu_oracle_seconds_1_thread": round(cpu, 2),
                      "reached": int((got != x0[1]).sum()) if name == "sssp" else int((got != 0).sum())}

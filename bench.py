@@ -34,8 +34,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 
 # HBM bytes per SpMV launch measured in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
 # WRITE_SIZE, MI355X_MICROARCH.md "HBM"); PMC cannot be collected inside this process.  Keyed by
-# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_v4_powerlaw.txt
-MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 2429980262}
+# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_v5_powerlaw.txt
+MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 2430943642}
 
 WORKLOADS = {
     # name: (kind, rows, nnz, description)
@@ -195,8 +195,8 @@ def main():
                      "traffic": (args.traffic_bytes if args.traffic_bytes is not None else
                                  (None if (args.rows or args.nnz) else
                                   MEASURED_TRAFFIC_BYTES.get((args.workload, A.plan()[0], world)))),
-                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_v4_powerlaw.txt",
-                     "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2s + spmv_heavy_fixup <PlusTimesF32> (one SpMV = these 3 launches; the fixup runs beside phase 2 on a side stream)" if A.plan()[0] == "tiled"
+                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_v5_powerlaw.txt",
+                     "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)" if A.plan()[0] == "tiled"
                                 else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
                      "rank": rank, "rank_nnz": s_nnz},

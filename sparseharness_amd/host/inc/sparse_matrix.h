@@ -82,6 +82,9 @@ public:
 
 private:
   void load_from_file(const std::string &filename);
+  // binary CSR cache next to the file (SH_CSR_CACHE=1 | <dir>), validated by the file's size + mtime
+  bool load_from_cache(const std::string &filename);
+  void store_to_cache(const std::string &filename) const;
   static bool &truncate_flag();
   static bool &keep_flag();
 

@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <cctype>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <type_traits>
 #include <cmath>
 #include <limits>
 #include <stdexcept>
@@ -171,7 +174,97 @@ template <typename T> bool &SparseMatrix<T>::keep_flag() {
   return flag;
 }
 
-template <typename T> SparseMatrix<T>::SparseMatrix(std::string filename) { load_from_file(filename); }
+// ---- binary CSR cache --------------------------------------------------------
+// SH_CSR_CACHE=1 keeps the finished rows next to the matrix file as <file>.shcsr.<f32|i32>[.raw];
+// SH_CSR_CACHE=<dir> keeps them in that directory.  A cache file is used only if its header
+// matches the source file's size and mtime, the element type and the truncation mode; anything
+// else (or any short read) falls back to parsing, and the cache is rewritten.  Not used when the
+// file-order entries are kept (PageRank needs them).
+namespace {
+struct CacheHeader {
+  char magic[8];            // "SHCSR\0\1\0"
+  int32_t elem_is_int, truncated;
+  int64_t src_size, src_mtime_ns;
+  int32_t rows, cols, nonz;
+  uint32_t max_width;
+  int64_t nnz;
+};
+const char CACHE_MAGIC[8] = {'S', 'H', 'C', 'S', 'R', 0, 1, 0};
+
+bool source_stamp(const std::string &path, int64_t &size, int64_t &mtime_ns) {
+  struct stat st;
+  if (::stat(path.c_str(), &st) != 0) return false;
+  size = (int64_t)st.st_size;
+  mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+  return true;
+}
+
+std::string cache_path(const std::string &filename, bool is_int, bool truncated) {
+  const char *e = std::getenv("SH_CSR_CACHE");
+  if (!e || !e[0] || (e[0] == '0' && !e[1])) return "";
+  std::string suffix = std::string(".shcsr.") + (is_int ? "i32" : "f32") + (truncated ? "" : ".raw");
+  if (e[0] == '1' && !e[1]) return filename + suffix;
+  std::string base = filename.substr(filename.find_last_of('/') == std::string::npos ? 0 : filename.find_last_of('/') + 1);
+  return std::string(e) + "/" + base + suffix;
+}
+} // namespace
+
+template <typename T> bool SparseMatrix<T>::load_from_cache(const std::string &filename) {
+  const std::string cp = cache_path(filename, std::is_integral<T>::value, truncate());
+  if (cp.empty() || keep_flag()) return false;
+  int64_t size = 0, mtime = 0;
+  if (!source_stamp(filename, size, mtime)) return false;
+  FILE *f = std::fopen(cp.c_str(), "rb");
+  if (!f) return false;
+  CacheHeader h;
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, CACHE_MAGIC, 8) == 0 &&
+            h.elem_is_int == (int)std::is_integral<T>::value && h.truncated == (int)truncate() && h.src_size == size &&
+            h.src_mtime_ns == mtime && h.rows >= 0 && h.nnz >= 0;
+  if (ok) {
+    row_ptr_.resize((std::size_t)h.rows + 1);
+    col_idx_.resize((std::size_t)h.nnz);
+    val_.resize((std::size_t)h.nnz);
+    ok = std::fread(row_ptr_.data(), 4, row_ptr_.size(), f) == row_ptr_.size() &&
+         std::fread(col_idx_.data(), 4, col_idx_.size(), f) == col_idx_.size() &&
+         std::fread(val_.data(), 4, val_.size(), f) == val_.size() && row_ptr_[0] == 0 &&
+         row_ptr_[(std::size_t)h.rows] == h.nnz;
+  }
+  std::fclose(f);
+  if (!ok) {
+    row_ptr_.clear(); col_idx_.clear(); val_.clear();
+    return false;
+  }
+  rows = h.rows; cols = h.cols; nonz = h.nonz; max_width = h.max_width;
+  LOG_DEBUG("rows read from the binary cache ", cp);
+  return true;
+}
+
+template <typename T> void SparseMatrix<T>::store_to_cache(const std::string &filename) const {
+  const std::string cp = cache_path(filename, std::is_integral<T>::value, truncate());
+  if (cp.empty() || keep_flag()) return;
+  CacheHeader h{};
+  std::memcpy(h.magic, CACHE_MAGIC, 8);
+  h.elem_is_int = (int)std::is_integral<T>::value; h.truncated = (int)truncate();
+  if (!source_stamp(filename, h.src_size, h.src_mtime_ns)) return;
+  h.rows = rows; h.cols = cols; h.nonz = nonz; h.max_width = max_width; h.nnz = (int64_t)col_idx_.size();
+  const std::string tmp = cp + ".tmp" + std::to_string((long)::getpid());
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return;   // read-only dataset folder: just no cache
+  const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
+                  std::fwrite(row_ptr_.data(), 4, row_ptr_.size(), f) == row_ptr_.size() &&
+                  std::fwrite(col_idx_.data(), 4, col_idx_.size(), f) == col_idx_.size() &&
+                  std::fwrite(val_.data(), 4, val_.size(), f) == val_.size();
+  if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), cp.c_str()) != 0)
+    std::remove(tmp.c_str());
+}
+
+template <typename T> SparseMatrix<T>::SparseMatrix(std::string filename) {
+  if (load_from_cache(filename))
+    return;
+  load_from_file(filename);
+  if (rows > 0)
+    store_to_cache(filename);
+}
 
 template <typename T>
 SparseMatrix<T>::SparseMatrix(int r, int c, std::vector<int32_t> rp, std::vector<int32_t> ci, std::vector<T> va)

@@ -84,3 +84,31 @@ def test_scc_app_matches_reference(matrix_name, host_loop):
     fin = g["scc_final"]
     assert f"iterations={int(g['scc_meta'][0])} converged={int(g['scc_meta'][1])}" in res
     assert f"labels={len(set(fin.tolist()))} label_sum={int(fin.astype(np.int64).sum())}" in res
+
+
+def test_experiment_sweep_end_to_end(tmp_path):
+    """SURVEY 8f-4 on the GPU: run_all.py over 2 matrices x 2 kernel configs, then the SQL collector."""
+    import csv
+    import sys
+    scripts = os.path.join(ROOT, "scripts")
+    data = tmp_path / "data"
+    for name in ("matrix3", "matrix4"):
+        (data / name).mkdir(parents=True)
+        os.symlink(mtx(name), data / name / (name + ".mtx"))
+    (data / "datasets.txt").write_text("matrix3\nmatrix4\n")
+    kern = tmp_path / "kernels"
+    kern.mkdir()
+    for k in ("spmv.json", "spmv_chunk128.json"):
+        os.symlink(os.path.join(KERNELS, k), kern / k)
+    env = {k: v for k, v in os.environ.items() if k != "SH_QUIET_TIMERS"}
+    r = subprocess.run([sys.executable, os.path.join(scripts, "run_all.py"), str(data), os.path.join(HOST, "bin", "spmv_harness"),
+                        str(kern), os.path.join(KERNELS, "runfile.csv"), "0", str(tmp_path / "res"), "--experiment", "sweep1",
+                        "--trials", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-800:]
+    r = subprocess.run([sys.executable, os.path.join(scripts, "build_query.py"), str(tmp_path / "res"), "t", "--out",
+                        str(tmp_path / "q.sql"), "--csv", str(tmp_path / "q.csv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "4 INSERT statements" in r.stdout, r.stdout
+    rows = list(csv.DictReader(open(tmp_path / "q.csv")))
+    assert len(rows) == 4 * 4                                   # 3 raw trials + the median row per run
+    assert {r_["matrix"] for r_ in rows} == {"matrix3", "matrix4"} and {r_["experiment_id"] for r_ in rows} == {"sweep1"}
+    assert sum(r_["correct"] == "correct" for r_ in rows) == 12 and not any(r_["correct"] == "badvalues" for r_ in rows)

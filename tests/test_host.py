@@ -221,3 +221,45 @@ def test_cpp_host_mirror_selftest(tmp_path):
     r = subprocess.run([os.path.join(HOST, "bin", "host_selftest"), str(tmp_path)], capture_output=True, text=True,
                        env={**os.environ, "SH_QUIET_TIMERS": "1"})
     assert r.returncode == 0 and "all passed" in r.stdout, r.stdout[-800:]
+
+
+def test_binary_csr_cache_roundtrip_and_invalidation(tmp_path, monkeypatch):
+    """the rows are cached next to (or, here, away from) the file and only reused while the
+    source file's size and mtime are unchanged; a damaged cache falls back to parsing."""
+    import shutil
+    src = tmp_path / "m.mtx"
+    shutil.copyfile(mtx("matrix5"), src)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    fresh = H.mm_load(str(src))
+    monkeypatch.setenv("SH_CSR_CACHE", str(cache))
+    first = H.mm_load(str(src))
+    files = sorted(os.listdir(cache))
+    assert files == ["m.mtx.shcsr.f32"]
+    second = H.mm_load(str(src))                       # served from the cache
+    for a, b, c in zip(fresh, first, second):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(c))
+    # element type and truncation mode have their own cache files
+    H.mm_load(str(src), elem_is_int=True)
+    raw = H.mm_load(str(src), truncate=False)
+    assert sorted(os.listdir(cache)) == ["m.mtx.shcsr.f32", "m.mtx.shcsr.f32.raw", "m.mtx.shcsr.i32"]
+    assert not np.array_equal(raw[5], first[5])        # matrix5 has real values: untruncated rows differ
+    # proof that the cache is what is read: doctor a cached value, reload, see it
+    p = cache / "m.mtx.shcsr.f32"
+    blob = bytearray(p.read_bytes())
+    blob[-4:] = np.float32(12345.0).tobytes()
+    p.write_bytes(bytes(blob))
+    assert H.mm_load(str(src))[5][-1] == np.float32(12345.0)
+    # the source file changes -> stale cache ignored and rewritten
+    st = os.stat(src)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
+    again = H.mm_load(str(src))
+    np.testing.assert_array_equal(again[5], fresh[5])
+    assert H.mm_load(str(src))[5][-1] == fresh[5][-1]
+    # truncated cache file -> parse again
+    p.write_bytes(p.read_bytes()[:100])
+    np.testing.assert_array_equal(H.mm_load(str(src))[5], fresh[5])
+    # PageRank (needs file order) never goes through the cache
+    pr = H.mm_load(mtx("matrix3"), normalise=H.NORM_PAGERANK)
+    assert pr[0] == 20

@@ -668,8 +668,8 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
                           ? (m->n_vdict ? 3ull : 6ull) * m->stream_len + (uint64_t)(m->stream_len - m->light_len) /* gdest */ +
-                                4ull * m->light_len /* phase 1 */ + 7ull * m->light_len /* phase 2 */ +
-                                vec + 128ull * 1024 * m->n_chunks /* x tile per phase-1 workgroup (mostly L2) */
+                                4ull * m->light_len /* P written */ + 7ull * m->light_len /* phase 2: P, slot, gsrc */ +
+                                vec /* x once: a tile is re-staged per phase-1 workgroup, but out of its XCD's L2 */
                           : 8ull * m->nnz + vec;
   }
   return SH_OK;

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="override size (testing only; makes the number non-headline)")
     ap.add_argument("--nnz", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ablation", action="store_true",
+                    help="skip the extra timing of the same matrix with value coding off (N=1 only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (corrected); echoed into roofline.traffic")
     args = ap.parse_args()
@@ -181,6 +183,37 @@ def main():
               "rows_where_gold_itself_is_inexact_and_gpu_is_closer_to_exact": excused,
               "bit_exact_rows": int((y == want).sum())}
 
+    # ---- transparency leg (N=1): the same matrix without the one-byte value coding, i.e. the layout a
+    # matrix with more than 256 distinct values gets; NOT the reported value
+    ablation = None
+    if rank == 0 and world == 1 and not args.no_ablation and "values=dict8" in A.describe():
+        prev_vc = os.environ.get("SH_VALCODE")
+        os.environ["SH_VALCODE"] = "off"
+        try:
+            A_raw = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va)
+        finally:
+            if prev_vc is None:
+                os.environ.pop("SH_VALCODE", None)
+            else:
+                os.environ["SH_VALCODE"] = prev_vc
+        out2_t = torch.zeros_like(out_t)
+        out2 = eng.wrap(out2_t.data_ptr(), s_rows)
+        for _ in range(3):
+            eng.spmv(PLUS_TIMES_F32, A_raw, x, None, 1.0, 0.0, out2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(20):
+            eng.spmv(PLUS_TIMES_F32, A_raw, x, None, 1.0, 0.0, out2)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        raw_ms = e0.elapsed_time(e1) / 20
+        ablation = {"layout": A_raw.describe(), "ms_per_step": round(raw_ms, 6),
+                    "frac_of_peak": round(A.algorithmic_bytes(reads_y=False) / (raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "same_result_bits": bool(torch.equal(out2_t.view(torch.int32), out_t.view(torch.int32))),
+                    "note": "value coding off (SH_VALCODE=off): what a matrix with more than 256 distinct values runs at"}
+        A_raw.free()
+
     alg_bytes = A.algorithmic_bytes(reads_y=False)
     achieved = alg_bytes / (dev_ms_per_launch * 1e-3) / 1e9
     result = {
@@ -201,6 +234,7 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
                      "rank": rank, "rank_nnz": s_nnz},
         "cpu_baseline": cpu,
+        "ablation_raw_values": ablation,
         "parity": parity,
         "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": A.describe()},
         "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/envb
 i=0
 for envs in "$@"; do
   i=$((i+1))
-  env $envs python bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS 2>/dev/null > gpurun_out/envb/$i.json
+  env $envs python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ablation $BENCH_ARGS 2>/dev/null > gpurun_out/envb/$i.json
   python - "$envs" gpurun_out/envb/$i.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

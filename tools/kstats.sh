@@ -2,7 +2,7 @@
 # tools/kstats.sh <outdir> [bench args] -- rocprofv3 kernel-trace stats of a short bench run, summary to stdout
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ablation "$@" > $out/bench.json 2> $out/err.log
 python3 - $out <<'PY'
 import csv, glob, sys
 for r in csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0])):

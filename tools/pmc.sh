@@ -4,7 +4,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/$ctr.json 2> $out/$ctr.err
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ablation "$@" > $out/$ctr.json 2> $out/$ctr.err
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections

@@ -2,7 +2,7 @@
 # tools/pmc_sq.sh <outdir> "<counters>" [bench args] -- SQ counters per kernel (one pass)
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; ctrs="$2"; shift; shift
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ablation "$@" > $out/bench.json 2> $out/err.log
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")

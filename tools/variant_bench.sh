@@ -4,7 +4,7 @@
 out=gpurun_out/variants; mkdir -p $out
 for lib in sparseharness_amd/libsparseharness_hip.so sparseharness_amd/variants/*.so; do
   name=$(basename $lib .so)
-  SH_LIB=$PWD/$lib python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null > $out/$name.json
+  SH_LIB=$PWD/$lib python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ablation "$@" 2>/dev/null > $out/$name.json
   python - "$name" "$out/$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

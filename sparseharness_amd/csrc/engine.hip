@@ -270,7 +270,7 @@ struct TiledHost {
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, int n_cus, TiledHost &H) {
-  const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) >> TCOLS_LOG2);
+  const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
   int64_t per_tile = 8;
@@ -278,7 +278,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // (capped at TBIN/4 so that a single light row fits a bin even when every entry is padded to 4)
   const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
-  auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c >> TCOLS_LOG2) : 0; };
+  auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c / TCOLS) : 0; };
 
   // 1. light row offsets (heavy rows have light length 0 and carry bit 31) and row bins
   H.lrp.assign((size_t)rows + 1, 0u);
@@ -419,7 +419,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     const bool in_range = (uint32_t)c < (uint32_t)cols;
     if (coded) H.tcode[(size_t)pos] = (uint8_t)hcode[vfind(val[j])];
     else H.tval[(size_t)pos] = val[j];
-    H.tcol[(size_t)pos] = in_range ? (uint16_t)(c & (TCOLS - 1)) : TCOL_IDENTITY;
+    H.tcol[(size_t)pos] = in_range ? (uint16_t)(c % TCOLS) : TCOL_IDENTITY;
   };
   for (auto &b : H.bins) {
     touched.clear();
@@ -683,7 +683,7 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     if (m->n_vdict) snprintf(vals, sizeof vals, "dict8(%d)", m->n_vdict_used);
     else snprintf(vals, sizeof vals, "raw");
     snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM", vals,
-             (long long)((m->cols + TCOLS - 1) >> TCOLS_LOG2), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
+             (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
              m->light_len / 1e6);
   } else {
     snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);

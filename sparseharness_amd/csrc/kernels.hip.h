@@ -412,8 +412,10 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 // HBM bytes per entry: 4+2+1 read, 4 written (phase 1), 4+2 read (phase 2)
 // = 17 B vs the 8 B algorithmic, but all of it is streaming.
 // ===========================================================================
-constexpr int TCOLS_LOG2 = 15;
-constexpr int TCOLS = 1 << TCOLS_LOG2;  // columns per x tile (128 KiB of LDS)
+#ifndef SH_TCOLS
+#define SH_TCOLS 32768
+#endif
+constexpr int TCOLS = SH_TCOLS;         // columns per x tile (4 B each in LDS); a multiple of 4, < 65536
 constexpr int TBS = 1024;               // threads per phase-1 workgroup
 #ifndef SH_TBIN
 #define SH_TBIN 16384   // 32768: one 1024-thread WG per CU; 16384: two 512-thread WGs (measured 5 % faster)
@@ -429,9 +431,9 @@ constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #endif
 constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
-constexpr uint16_t TCOL_IDENTITY = 0x8000; // col16 code of "x reads as the identity": == TCOLS, the LDS slot holding it
+constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
-static_assert(TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
+static_assert(TCOLS % 4 == 0 && TCOLS < 65536 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
 constexpr uint32_t THEAVY = 0x80000000u;   // gdest flag: group belongs to a heavy row, low bits = partial slot
 
 // entries [s,e) of the tile-major stream; positions >= hs belong to heavy rows (each tile's stream
@@ -463,7 +465,10 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   constexpr int U = VC ? P1U_VC : P1U;
   using VWord = typename std::conditional<VC, uint32_t, uint4>::type;   // 4 codes or 4 values
   // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
-  __shared__ uint32_t xs[TCOLS + 4];
+#ifndef SH_XS_EXTRA
+#define SH_XS_EXTRA 0
+#endif
+  __shared__ uint32_t xs[TCOLS + 4 + SH_XS_EXTRA];
   __shared__ uint32_t ds[VC ? VDICT : 1];
   const VWord *__restrict__ tval = reinterpret_cast<const VWord *>(tval_or_code);
   const uint2 *__restrict__ tcol2 = reinterpret_cast<const uint2 *>(tcol);
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   if (ch.s >= ch.e)
     return;   // filler that keeps the XCD-aligned chunk order
   const int tid = threadIdx.x;
-  const int c0 = ch.tile << TCOLS_LOG2;
+  const int c0 = ch.tile * TCOLS;
   const uint32_t ident = to_bits<T>(SR::identity());
   if (VC && tid < VDICT)
     ds[tid] = vdict[tid];
@@ -479,8 +484,17 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     xs[TCOLS] = ident;
   // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
   if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    for (int i = tid; i < TCOLS / 4; i += TBS)   // full tile, 16-byte aligned: 1 KiB per wave-instruction
-      reinterpret_cast<uint4 *>(xs)[i] = reinterpret_cast<const uint4 *>(x + c0)[i];
+    // full tile, 16-byte aligned: 1 KiB per wave-instruction; every load is issued before the first
+    // LDS write (a rolled loop would pay one memory latency per iteration)
+    constexpr int NI = (TCOLS / 4 + TBS - 1) / TBS;
+    uint4 t[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++)
+      t[k] = reinterpret_cast<const uint4 *>(x + c0)[min(tid + k * TBS, TCOLS / 4 - 1)];
+#pragma unroll
+    for (int k = 0; k < NI; k++)
+      if (tid + k * TBS < TCOLS / 4)
+        reinterpret_cast<uint4 *>(xs)[tid + k * TBS] = t[k];
   } else {
     for (int i = tid; i < TCOLS; i += TBS)
       xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;

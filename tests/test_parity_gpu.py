@@ -435,3 +435,55 @@ def test_iteration_cap_on_a_graph_that_never_settles(eng):
     iters, conv, per, _ = eng.iterate(O.OR_AND_I32, A, x, y, sc, 1, 0, 1e-4, 7)
     assert (iters, conv, len(per)) == (7, False, 7)
     np.testing.assert_array_equal(x.download(np.int32), want)
+
+
+# ------------------------------------------------------------------ (c) randomised shapes (hypothesis)
+def _random_csr(rng, rows, cols, nnz, n_heavy, frac_empty, frac_oob):
+    """Ragged CSR with a few very long rows, a share of empty rows and some out-of-range columns."""
+    w = rng.random(rows) ** 3
+    w[rng.random(rows) < frac_empty] = 0
+    if w.sum() == 0:
+        w[0] = 1
+    deg = rng.multinomial(nnz, w / w.sum())
+    for h in rng.integers(0, rows, n_heavy):
+        deg[h] += int(rng.integers(3_000, 20_000))
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    ci = rng.integers(0, cols, rp[-1]).astype(np.int32)
+    oob = rng.random(rp[-1]) < frac_oob
+    ci[oob] = rng.choice(np.array([-1, -7, cols, cols + 12345], np.int32), int(oob.sum()))
+    return rp, ci
+
+
+def test_random_shapes_match_oracle_bit_for_bit(eng):
+    """Property test over matrix shapes: integer-valued data, so every semiring is exact in any order."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2**31 - 1), rows=st.integers(1, 60_000), cols=st.integers(1, 400_000),
+           density=st.floats(0.2, 40.0), n_heavy=st.integers(0, 3), frac_empty=st.floats(0.0, 0.6),
+           frac_oob=st.sampled_from([0.0, 0.0, 0.01]))
+    def check(seed, rows, cols, density, n_heavy, frac_empty, frac_oob):
+        rng = np.random.default_rng(seed)
+        nnz = max(1, min(int(rows * density), 1_500_000))
+        rp, ci = _random_csr(rng, rows, cols, nnz, n_heavy, frac_empty, frac_oob)
+        nvals = int(rng.choice([1, 16, 300]))             # pattern-like / coded / raw value layouts
+        # multiples of 1/64 below 4.7, x in {0,1}: every partial sum is exact in float (< 2^18), so the
+        # result does not depend on the summation order and must match bit for bit
+        va = (rng.integers(1, nvals + 1, rp[-1]) / 64.0).astype(np.float32)
+        x = rng.integers(0, 2, cols).astype(np.float32)
+        y = rng.integers(0, 9, rows).astype(np.float32)
+        got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, x, y, 2.0, 1.0, cols=cols)
+        want = O.kernel(O.PLUS_TIMES_F32, rp, ci, va, x, y, 2.0, 1.0, vlength=cols)
+        np.testing.assert_array_equal(bits(got), bits(want))
+        xs = np.where(rng.random(cols) < 0.3, np.float32(3.4028235e38), x)          # (min,+) with unreached sources
+        ys = np.where(rng.random(rows) < 0.5, np.float32(3.4028235e38), y)
+        got = run_spmv(eng, O.MIN_PLUS_F32, rp, ci, va, xs, ys, 0.0, 0.0, cols=cols)
+        want = O.kernel(O.MIN_PLUS_F32, rp, ci, va, xs, ys, 0.0, 0.0, vlength=cols)
+        np.testing.assert_array_equal(bits(got), bits(want))
+        xi, yi, vi = x.astype(np.int32), y.astype(np.int32), ((va * 64).astype(np.int32) - 1)  # zeros among the values
+        got = run_spmv(eng, O.OR_AND_I32, rp, ci, vi, xi, yi, 1, 1, cols=cols)
+        np.testing.assert_array_equal(got, O.kernel(O.OR_AND_I32, rp, ci, vi, xi, yi, 1, 1, vlength=cols))
+        got = run_spmv(eng, O.MAX_MIN_I32, rp, ci, vi - 5, xi - 2, yi, 7, -3, cols=cols)
+        np.testing.assert_array_equal(got, O.kernel(O.MAX_MIN_I32, rp, ci, vi - 5, xi - 2, yi, 7, -3, vlength=cols))
+
+    check()

@@ -122,7 +122,10 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
 /* One-line description of the layout built at upload, for logs and bench records, e.g.
  * "tiled values=dict8(16) tiles=306 chunks=6416 bins=8532 heavy_rows=5276 stream=200.9M light=138.3M".
  * values=dict8(k): the matrix has k <= 256 distinct 4-byte values and the tiled stream carries
- * one-byte codes (lossless; SH_VALCODE=off keeps raw values); values=raw otherwise. */
+ * one-byte codes (lossless; SH_VALCODE=off keeps raw values); values=raw otherwise.
+ * " tuned(stream=..ms,tiled=..ms)" is appended when the plan was confirmed by timing both at upload:
+ * large matrices get the tiled plan by size, unless the CSR-stream plan runs > 10 % faster on the
+ * device (matrices with local columns); SH_PLAN=stream|tiled or SH_AUTOTUNE=0 skip the timing. */
 int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen);
 
 /* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /

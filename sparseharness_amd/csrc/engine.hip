@@ -50,6 +50,8 @@ struct sh_csr {
   uint32_t *d_partial = nullptr;
   // x-tiled two-phase plan (kernels.hip.h); built when plan == PLAN_TILED
   int plan = 0;
+  bool tuned = false;           // plan confirmed by timing both at upload (autotune_plan)
+  float tuned_ms[2] = {0, 0};   // [stream, tiled]
   RowBin *d_bins = nullptr;
   int32_t n_bins = 0;
   TileChunk *d_chunks = nullptr;
@@ -502,6 +504,52 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   return true;
 }
 
+static int dispatch(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
+                    const void *alpha, const void *beta, sh_vec *out, StepDev st);
+
+// The size rule picks the tiled plan for every large matrix, but a large matrix whose columns are
+// local (banded, FEM-like) keeps its x window in L2 and streams 8 B/entry under plan A, which the
+// tiled plan cannot match.  So when the rule says "tiled" and nobody forced a plan, both are
+// timed once on the device (x = 0: the memory behaviour of a launch does not depend on the values)
+// and plan A is kept only if it is clearly faster -- 10 % -- so that near-ties, where the two
+// plans' float rounding of heavy rows could differ, always resolve the same way.
+static void autotune_plan(sh_engine *e, sh_csr *m) {
+  sh_vec xv, ov;
+  if (hipMalloc(&xv.d, (size_t)std::max<int64_t>(m->cols, 1) * 4) != hipSuccess) return;
+  if (hipMalloc(&ov.d, (size_t)std::max<int64_t>(m->rows, 1) * 4) != hipSuccess) { (void)hipFree(xv.d); return; }
+  xv.n = m->cols; ov.n = m->rows;
+  (void)hipMemsetAsync(xv.d, 0, (size_t)std::max<int64_t>(m->cols, 1) * 4, e->stream);
+  const float one = 1.0f, zero = 0.0f;
+  float ms[2] = {0, 0};
+  bool ok = true;
+  for (int plan : {PLAN_TILED, PLAN_STREAM}) {
+    m->plan = plan;
+    for (int rep = 0; rep < 3 && ok; rep++) {   // one warm-up, then the faster of two
+      ok = hipEventRecord(e->ev0, e->stream) == hipSuccess &&
+           dispatch(e, SH_PLUS_TIMES_F32, m, &xv, nullptr, &one, &zero, &ov, StepDev{nullptr, nullptr, 0, 0.0}) == SH_OK &&
+           hipEventRecord(e->ev1, e->stream) == hipSuccess && hipEventSynchronize(e->ev1) == hipSuccess;
+      float t = 0;
+      if (ok) ok = hipEventElapsedTime(&t, e->ev0, e->ev1) == hipSuccess;
+      if (ok && rep > 0) ms[plan] = (rep == 1) ? t : std::min(ms[plan], t);
+    }
+  }
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(xv.d);
+  (void)hipFree(ov.d);
+  m->plan = (ok && ms[PLAN_STREAM] < 0.9f * ms[PLAN_TILED]) ? PLAN_STREAM : PLAN_TILED;
+  if (m->plan == PLAN_STREAM) {   // the tiled layout is of no further use
+    for (void **p : {(void **)&m->d_bins, (void **)&m->d_chunks, (void **)&m->d_tval, (void **)&m->d_tcol, (void **)&m->d_gdest,
+                     (void **)&m->d_pslot, (void **)&m->d_gsrc, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
+                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+  }
+  m->tuned = ok;
+  m->tuned_ms[0] = ms[PLAN_STREAM];
+  m->tuned_ms[1] = ms[PLAN_TILED];
+}
+
 static int choose_plan(int64_t cols, int64_t nnz) {
   const char *e = getenv("SH_PLAN");
   if (e && !strcmp(e, "stream")) return PLAN_STREAM;
@@ -617,6 +665,13 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
   }
   HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
 #undef HIP_TRY_M
+  {
+    const char *forced = getenv("SH_PLAN");
+    const char *tune = getenv("SH_AUTOTUNE");
+    if (m->plan == PLAN_TILED && !(forced && (!strcmp(forced, "stream") || !strcmp(forced, "tiled"))) &&
+        !(tune && tune[0] == '0'))
+      autotune_plan(e, m);
+  }
   *out = m;
   return SH_OK;
 }
@@ -687,6 +742,10 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
              m->light_len / 1e6);
   } else {
     snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);
+  }
+  if (m->tuned) {
+    const size_t len = strlen(buf);
+    snprintf(buf + len, buflen - len, " tuned(stream=%.3fms,tiled=%.3fms)", m->tuned_ms[0], m->tuned_ms[1]);
   }
   return SH_OK;
 }

@@ -298,6 +298,35 @@ def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
         A.free()
 
 
+def test_upload_times_both_plans_for_large_matrices(eng, plan, monkeypatch):
+    """Size alone says "tiled" for any large matrix; a banded one keeps its x window in L2 and is faster under
+    the CSR-stream plan, a random one is not: the upload-time measurement must tell them apart."""
+    if plan != "stream":
+        pytest.skip("runs once, with SH_PLAN unset")
+    monkeypatch.delenv("SH_PLAN")
+    rng = np.random.default_rng(3)
+    n, per_row = 3_000_000, 8
+    rp = (np.arange(n + 1, dtype=np.int64) * per_row).astype(np.int32)
+    va = rng.integers(1, 17, n * per_row).astype(np.float32)
+    x = (1 + np.arange(n) % 7).astype(np.float32)
+    band = (np.repeat(np.arange(n, dtype=np.int64), per_row) + rng.integers(-300, 301, n * per_row)).clip(0, n - 1).astype(np.int32)
+    rand = rng.integers(0, n, n * per_row).astype(np.int32)
+    for ci, want_plan in ((band, "stream"), (rand, "tiled")):
+        A = eng.upload_csr(n, n, rp, ci, va)
+        d = A.describe()
+        assert "tuned(stream=" in d and A.plan()[0] == want_plan, d
+        xv, out = eng.vector(x), eng.alloc(n).fill(0)
+        eng.spmv(O.PLUS_TIMES_F32, A, xv, None, 1.0, 0.0, out)
+        np.testing.assert_array_equal(bits(out.download(np.float32)), bits(O.gold_dot(rp, ci, va, x)))
+        for v in (xv, out):
+            v.free()
+        A.free()
+    monkeypatch.setenv("SH_AUTOTUNE", "0")
+    A = eng.upload_csr(n, n, rp, band, va)
+    assert "tuned" not in A.describe() and A.plan()[0] == "tiled"
+    A.free()
+
+
 def test_rectangular_and_wide_matrices(eng):
     """rows != cols (the C ABI allows it; only the apps insist on square) and x spanning many tiles."""
     rng = np.random.default_rng(99)

@@ -864,7 +864,8 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());
-    static const bool classic_p2 = [] { const char *v = getenv("SH_P2"); return v && !strcmp(v, "classic"); }();
+    const char *p2 = getenv("SH_P2");
+    const bool classic_p2 = p2 && !strcmp(p2, "classic");
     if (!classic_p2 && A->n_bins > 0) {
       // wave-specialised phase 2; its reducer waves also add up the heavy rows' partials while
       // the loaders fill the first image, so one SpMV is two launches

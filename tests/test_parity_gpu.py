@@ -327,6 +327,23 @@ def test_upload_times_both_plans_for_large_matrices(eng, plan, monkeypatch):
     A.free()
 
 
+@pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])
+def test_classic_phase2_kernel_still_matches(eng, cases, name, plan, monkeypatch):
+    """SH_P2=classic keeps the previous phase-2 kernel (+ the stand-alone heavy-row fixup on a side stream)
+    selectable for A/B runs; it must stay correct."""
+    if plan != "tiled":
+        pytest.skip("phase 2 belongs to the tiled plan")
+    monkeypatch.setenv("SH_P2", "classic")
+    rp, ci, va, n = cases[name]
+    xm = (1 + np.arange(n) % 7).astype(np.float32)
+    ym = (np.arange(n) % 5).astype(np.float32)
+    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)
+    np.testing.assert_array_equal(bits(got), bits(O.kernel(O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)))
+    x0 = O.initial_vector(O.MIN_PLUS_F32, n)
+    got = run_spmv(eng, O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)
+    np.testing.assert_array_equal(bits(got), bits(O.kernel(O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)))
+
+
 def test_rectangular_and_wide_matrices(eng):
     """rows != cols (the C ABI allows it; only the apps insist on square) and x spanning many tiles."""
     rng = np.random.default_rng(99)

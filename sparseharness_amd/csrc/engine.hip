@@ -18,6 +18,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 using namespace sh;
 
@@ -100,6 +102,56 @@ static int fail(sh_engine *e, int code, const char *fmt, ...) {
                   "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r),        \
                   __FILE__, __LINE__);                                          \
   } while (0)
+
+// Host threads for the plan build: SH_BUILD_THREADS, else the hardware's, at most 16.
+static int build_threads() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (const char *e = getenv("SH_BUILD_THREADS")) n = atoi(e);
+  return std::max(1, std::min(n, 16));
+}
+// fn(item, thread) for every item in [0, n): items are handed out `grain` at a time from an atomic
+// counter (bins and heavy rows differ a lot in size), on `threads` std::threads (no OpenMP: the
+// library lives in processes that already carry an OpenMP runtime of their own)
+template <class F> static void parallel_items(int64_t n, int64_t grain, int threads, F fn) {
+  threads = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (n + grain - 1) / grain));
+  if (threads <= 1) {
+    for (int64_t i = 0; i < n; i++) fn(i, 0);
+    return;
+  }
+  std::atomic<int64_t> next{0};
+  auto worker = [&](int th) {
+    for (;;) {
+      const int64_t i0 = next.fetch_add(grain);
+      if (i0 >= n) return;
+      for (int64_t i = i0; i < std::min(n, i0 + grain); i++) fn(i, th);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
+  worker(0);
+  for (auto &t : pool) t.join();
+}
+
+// Small open-addressing set of 4-byte value words with first-come codes (value dictionary of the tiled plan).
+struct ValSet {
+  static constexpr uint32_t VH = 2048, VEMPTY = 0xFFFFFFFFu;
+  std::vector<uint32_t> key, code, list;
+  bool overflow = false;
+  ValSet() : key(VH, 0u), code(VH, VEMPTY) {}
+  static uint32_t hash(uint32_t b) { return (b * 2654435761u) >> 21; }   // 11 bits
+  uint32_t find(uint32_t b) const {   // slot holding b, or the empty slot where it belongs
+    uint32_t h = hash(b);
+    while (code[h] != VEMPTY && key[h] != b) h = (h + 1) & (VH - 1);
+    return h;
+  }
+  void add(uint32_t b) {
+    const uint32_t h = find(b);
+    if (code[h] != VEMPTY) return;
+    if (list.size() == (size_t)VDICT) { overflow = true; return; }
+    key[h] = b; code[h] = (uint32_t)list.size();
+    list.push_back(b);
+  }
+};
 
 extern "C" {
 
@@ -311,173 +363,199 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     r = r1;
   }
 
-  // 2. sweep A.  Each tile's stream is [light pieces, bins in order][heavy pieces, rows in order];
-  //    everything is padded to groups of 4.  A1 sizes the light pieces (-> bin.n, bin.pstart,
-  //    light_total[t]); A2 walks the heavy rows: hrel[t] is the running position inside tile t,
-  //    which fixes where the 64-group wave boundaries of phase 1 fall, hence how a heavy
-  //    (row, tile) piece splits into partials.
-  std::vector<int32_t> count(CT, 0);
-  std::vector<int32_t> touched;
-  std::vector<int64_t> light_total(CT, 0), hrel(CT, 0);
+  // 2.-3. The layout.  Each tile's stream is [light pieces, bins in order][heavy pieces, rows in
+  //    order]; every piece is padded to groups of 4.  Built in passes so that the O(nnz) walks run on
+  //    several host threads (work items handed out dynamically; each writes only its own bin's or
+  //    row's ranges) and only O(pieces) prefix sums stay sequential:
+  //      P1 (parallel, bins)        count each bin's entries per tile -> its piece list, bin.n
+  //      P2 (parallel, heavy rows)  the same per heavy row
+  //      S1 (sequential)            bin.pstart, per-tile totals; position of every light piece
+  //      S2 (sequential)            heavy pieces: hrel[t] is the running position inside tile t, which
+  //                                 fixes where the 64-group wave boundaries of phase 1 fall, hence how
+  //                                 a heavy (row, tile) piece splits into partials
+  //      P3 (parallel)              value dictionary (per-thread sets, merged)
+  //      P4 (parallel, bins)        fill the light stream, pslot, gsrc
+  //      P5 (parallel, heavy rows)  fill the heavy stream and gdest
+  struct Piece { int32_t tile, cnt; int64_t pos; int32_t part0; };   // pos: stream position; part0: first partial (heavy)
+  const int64_t n_bins = (int64_t)H.bins.size();
+  std::vector<std::vector<Piece>> bin_pieces((size_t)n_bins);
+  std::vector<int64_t> heavy_rows_idx;
+  for (int64_t r = 0; r < rows; r++)
+    if (is_heavy(r)) heavy_rows_idx.push_back(r);
+  const int64_t n_heavy = (int64_t)heavy_rows_idx.size();
+  std::vector<std::vector<Piece>> heavy_pieces((size_t)n_heavy);
   auto parts_of = [](int64_t rel_start, int32_t padded) -> int32_t {   // 64-group blocks spanned
     const int64_t g0 = rel_start / 4, g1 = (rel_start + padded) / 4 - 1;
     return (int32_t)(g1 / 64 - g0 / 64 + 1);
   };
-  auto count_row = [&](int64_t r) {
-    for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
-      const int t = tile_of(ci[j]);
-      if (count[t]++ == 0) touched.push_back(t);
+  const int NT = build_threads();
+  struct Scratch { std::vector<int32_t> count, touched; std::vector<int64_t> pos; };
+  std::vector<Scratch> scratch((size_t)NT);
+  for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
+  // pieces of the rows [ra, rb) that satisfy `want` (light / heavy), tiles ascending
+  auto collect = [&](Scratch &sc, int64_t ra, int64_t rb, bool want_heavy, std::vector<Piece> &out) {
+    sc.touched.clear();
+    for (int64_t r = ra; r < rb; r++) {
+      if (is_heavy(r) != want_heavy) continue;
+      for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
+        const int t = tile_of(ci[j]);
+        if (sc.count[(size_t)t]++ == 0) sc.touched.push_back(t);
+      }
+    }
+    std::sort(sc.touched.begin(), sc.touched.end());
+    out.clear();
+    out.reserve(sc.touched.size());
+    for (int t : sc.touched) {
+      out.push_back(Piece{t, sc.count[(size_t)t], 0, 0});
+      sc.count[(size_t)t] = 0;
     }
   };
-  int64_t p_off = 0;
-  for (auto &b : H.bins) {
-    touched.clear();
-    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++)
-      if (!is_heavy(r)) count_row(r);
+  // P1
+  parallel_items(n_bins, 8, NT, [&](int64_t bi, int th) {
+    RowBin &b = H.bins[(size_t)bi];
+    collect(scratch[(size_t)th], b.r0, (int64_t)b.r0 + b.nr, false, bin_pieces[(size_t)bi]);
     int64_t n = 0;
-    for (int t : touched) {
-      const int32_t padded = (count[t] + 3) & ~3;
-      n += padded;
-      light_total[t] += padded;
-      count[t] = 0;
-    }
+    for (const Piece &pc : bin_pieces[(size_t)bi]) n += (pc.cnt + 3) & ~3;
     b.n = (int32_t)n;
-    if (n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
-    if (p_off + n > INT32_MAX) return false;
+  });
+  // P2
+  parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
+    const int64_t r = heavy_rows_idx[(size_t)hi];
+    collect(scratch[(size_t)th], r, r + 1, true, heavy_pieces[(size_t)hi]);
+  });
+  // S1 (positions are relative to the tile start until the tile starts are known)
+  std::vector<int64_t> light_total(CT, 0), hrel(CT, 0);
+  int64_t p_off = 0;
+  for (int64_t bi = 0; bi < n_bins; bi++) {
+    RowBin &b = H.bins[(size_t)bi];
+    if (b.n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
+    if (p_off + b.n > INT32_MAX) return false;
     b.pstart = (int32_t)p_off;
-    p_off += n;
+    p_off += b.n;
+    for (Piece &pc : bin_pieces[(size_t)bi]) {
+      pc.pos = light_total[(size_t)pc.tile];
+      light_total[(size_t)pc.tile] += (pc.cnt + 3) & ~3;
+    }
   }
   H.p_len = p_off;
   H.light_len = p_off;
+  // S2
   for (int t = 0; t < CT; t++) hrel[t] = light_total[t];
-  for (int64_t r = 0; r < rows; r++) {
-    if (!is_heavy(r)) continue;
-    touched.clear();
-    count_row(r);
-    int32_t np = 0;
-    for (int t : touched) {
-      const int32_t padded = (count[t] + 3) & ~3;
-      np += parts_of(hrel[t], padded);
-      hrel[t] += padded;
-      count[t] = 0;
+  H.heavy.resize((size_t)n_heavy);
+  {
+    int64_t slots = 0;
+    for (int64_t hi = 0; hi < n_heavy; hi++) {
+      int32_t np = 0;
+      for (Piece &pc : heavy_pieces[(size_t)hi]) {
+        const int32_t padded = (pc.cnt + 3) & ~3;
+        pc.pos = hrel[(size_t)pc.tile];
+        pc.part0 = np;
+        np += parts_of(pc.pos, padded);
+        hrel[(size_t)pc.tile] += padded;
+      }
+      H.heavy[(size_t)hi] = LongRow{(int32_t)heavy_rows_idx[(size_t)hi], (int32_t)slots, np, 0};
+      slots += np;
+      if (slots > 0x7FFFFFF0ll) return false;
     }
-    LongRow lr{(int32_t)r, 0, np, 0};
-    H.heavy.push_back(lr);
+    H.n_partials = (int32_t)slots;
   }
   int64_t total = 0;
-  std::vector<int64_t> tile_start(CT, 0);
-  for (int t = 0; t < CT; t++) { tile_start[t] = total; total += hrel[t]; }   // hrel = light + heavy
+  std::vector<int64_t> tile_start(CT, 0), heavy_start(CT, 0);
+  for (int t = 0; t < CT; t++) { tile_start[t] = total; heavy_start[t] = total + light_total[t]; total += hrel[t]; }   // hrel = light + heavy
   if (total > INT32_MAX - 8) return false;
   H.stream_len = total;
   if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
     return false; // padding would cost more than 25 %: keep the stream plan
-  {
-    int64_t acc = 0;
-    for (auto &lr : H.heavy) { lr.slot0 = (int32_t)acc; acc += lr.nslots; }
-    if (acc > 0x7FFFFFF0ll) return false;
-    H.n_partials = (int32_t)acc;
-  }
 
-  // value dictionary: <= VDICT distinct bit patterns (code 0 = the all-zero word, used by padding)
+  // P3: value dictionary: <= VDICT distinct bit patterns (code 0 = the all-zero word, used by padding)
   // => the stream carries one-byte codes.  SH_VALCODE=off keeps raw values.
-  constexpr uint32_t VH = 2048, VEMPTY = 0xFFFFFFFFu;
-  std::vector<uint32_t> hkey(VH, 0u), hcode(VH, VEMPTY);
-  auto vhash = [](uint32_t b) { return (b * 2654435761u) >> 21; };   // 11 bits
-  auto vfind = [&](uint32_t b) -> uint32_t {   // slot holding b, or the empty slot where it belongs
-    uint32_t h = vhash(b);
-    while (hcode[h] != VEMPTY && hkey[h] != b) h = (h + 1) & (VH - 1);
-    return h;
-  };
+  ValSet dict;
   {
     const char *vc = getenv("SH_VALCODE");
     bool coded = !(vc && !strcmp(vc, "off"));
     if (coded) {
-      H.vdict.assign(1, 0u);
-      hkey[vfind(0u)] = 0u; hcode[vfind(0u)] = 0u;
-      for (int64_t j = 0; j < nnz && coded; j++) {
-        const uint32_t h = vfind(val[j]);
-        if (hcode[h] == VEMPTY) {
-          if (H.vdict.size() == (size_t)VDICT) { coded = false; break; }
-          hkey[h] = val[j]; hcode[h] = (uint32_t)H.vdict.size();
-          H.vdict.push_back(val[j]);
-        }
+      std::vector<ValSet> part((size_t)NT);
+      parallel_items((nnz + 65535) / 65536, 4, NT, [&](int64_t blk, int th) {
+        ValSet &vs = part[(size_t)th];
+        const int64_t e = std::min<int64_t>(nnz, (blk + 1) * 65536);
+        for (int64_t j = blk * 65536; j < e && !vs.overflow; j++) vs.add(val[j]);
+      });
+      dict.add(0u);
+      for (const ValSet &vs : part) {
+        if (vs.overflow) dict.overflow = true;
+        for (uint32_t b : vs.list) dict.add(b);
       }
+      // codes in ascending bit-pattern order: the same dictionary whatever the thread count
+      if (!dict.overflow) {
+        std::vector<uint32_t> sorted(dict.list);
+        std::sort(sorted.begin(), sorted.end());
+        ValSet ordered;
+        for (uint32_t b : sorted) ordered.add(b);
+        dict = ordered;
+      }
+      coded = !dict.overflow;
     }
-    if (!coded) H.vdict.clear();
+    if (coded) H.vdict = dict.list;
   }
   const bool coded = !H.vdict.empty();
 
-  // 3. sweep B: same walks, now filling the arrays
+  // P4 / P5: fill
   if (coded) { H.vdict_used = (int)H.vdict.size(); H.tcode.assign((size_t)H.stream_len, 0); H.vdict.resize(VDICT, 0u); }
   else H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)H.stream_len / 4, 0u);
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
   H.gsrc.assign((size_t)H.p_len / 4, 0u);
-  std::vector<int64_t> cursor(tile_start), piece_stream(CT, 0), piece_p(CT, 0);
-  std::vector<int32_t> fillpos(CT, 0);
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
     const bool in_range = (uint32_t)c < (uint32_t)cols;
-    if (coded) H.tcode[(size_t)pos] = (uint8_t)hcode[vfind(val[j])];
+    if (coded) H.tcode[(size_t)pos] = (uint8_t)dict.code[dict.find(val[j])];
     else H.tval[(size_t)pos] = val[j];
     H.tcol[(size_t)pos] = in_range ? (uint16_t)(c % TCOLS) : TCOL_IDENTITY;
   };
-  for (auto &b : H.bins) {
-    touched.clear();
-    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++)
-      if (!is_heavy(r)) count_row(r);
-    std::sort(touched.begin(), touched.end());
+  parallel_items(n_bins, 8, NT, [&](int64_t bi, int th) {
+    const RowBin &b = H.bins[(size_t)bi];
+    Scratch &sc = scratch[(size_t)th];
     int64_t off = b.pstart;
-    for (int t : touched) {
-      const int32_t padded = (count[t] + 3) & ~3;
-      piece_stream[t] = cursor[t];
-      piece_p[t] = off;
-      for (int32_t q = 0; q < padded; q += 4) {
-        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(cursor[t] + q);
-      }
-      cursor[t] += padded;
+    for (const Piece &pc : bin_pieces[(size_t)bi]) {
+      const int32_t padded = (pc.cnt + 3) & ~3;
+      const int64_t spos = tile_start[(size_t)pc.tile] + pc.pos;
+      for (int32_t q = 0; q < padded; q += 4)
+        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(spos + q);
+      sc.pos[(size_t)pc.tile] = spos;        // next free stream position of this (bin, tile) piece
+      sc.count[(size_t)pc.tile] = (int32_t)(off - spos);   // P position = stream position + this (fits: both < 2^31)
       off += padded;
-      fillpos[t] = 0;
-      count[t] = 0;
     }
     for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
       if (is_heavy(r)) continue;
       const int64_t slot0 = light_off(r) - b.csr0;
       for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
         const int t = tile_of(ci[j]);
-        const int32_t k = fillpos[t]++;
-        put_entry(piece_stream[t] + k, j);
-        H.pslot[(size_t)(piece_p[t] + k)] = (uint16_t)(slot0 + (j - rp[r]));
+        const int64_t pos = sc.pos[(size_t)t]++;
+        put_entry(pos, j);
+        H.pslot[(size_t)(pos + sc.count[(size_t)t])] = (uint16_t)(slot0 + (j - rp[r]));
       }
     }
-  }
-  // cursor[t] now sits at the start of tile t's heavy region
-  std::vector<int64_t> heavy_start(cursor);
-  for (const LongRow &lr : H.heavy) {
+    for (const Piece &pc : bin_pieces[(size_t)bi]) sc.count[(size_t)pc.tile] = 0;   // scratch back to all-zero
+  });
+  parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
+    const LongRow &lr = H.heavy[(size_t)hi];
     const int64_t r = lr.row;
-    touched.clear();
-    count_row(r);
-    std::sort(touched.begin(), touched.end());
-    int32_t part = lr.slot0;
-    for (int t : touched) {
-      const int32_t padded = (count[t] + 3) & ~3;
-      piece_stream[t] = cursor[t];
+    Scratch &sc = scratch[(size_t)th];
+    for (const Piece &pc : heavy_pieces[(size_t)hi]) {
+      const int32_t padded = (pc.cnt + 3) & ~3;
+      const int64_t spos = tile_start[(size_t)pc.tile] + pc.pos;
+      int32_t part = lr.slot0 + pc.part0;
       for (int32_t q = 0; q < padded; q += 4) {
-        const int64_t grel = (cursor[t] - tile_start[t] + q) / 4;   // group index inside the tile
+        const int64_t grel = (pc.pos + q) / 4;                     // group index inside the tile
         if (q > 0 && grel % 64 == 0) part++;                       // next wave of phase 1
-        H.gdest[(size_t)(cursor[t] + q) / 4] = (uint32_t)part;     // partial slot of this group
+        H.gdest[(size_t)(spos + q) / 4] = (uint32_t)part;          // partial slot of this group
       }
-      part++;
-      cursor[t] += padded;
-      fillpos[t] = 0;
-      count[t] = 0;
+      sc.pos[(size_t)pc.tile] = spos;
     }
-    for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
-      const int t = tile_of(ci[j]);
-      put_entry(piece_stream[t] + fillpos[t]++, j);
-    }
-  }
+    for (int32_t j = rp[r]; j < rp[r + 1]; j++)
+      put_entry(sc.pos[(size_t)tile_of(ci[j])]++, j);
+  });
   // 4. phase-1 work items.  Cuts are multiples of 64 groups from the tile start (so wave
   //    boundaries are the ones assumed above).  Order: workgroups are dealt round-robin over
   //    the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a

@@ -398,19 +398,23 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 //
 //   phase 1  (one workgroup per <= TCHUNK entries of one 32768-column tile)
 //     the x tile (128 KiB) is staged in LDS; the tile's entries, stored
-//     tile-major as {val f32, col u16}, are streamed with 16-byte loads,
-//     multiplied against LDS, and each aligned group of 4 products is stored
-//     with one 16-byte store into the product array P at a precomputed
-//     position (gdest, one u32 per 4 entries).
-//   phase 2  (one workgroup per row bin of <= TBIN products)
-//     P is laid out bin-major, so a bin's products are one contiguous stream;
-//     they are scattered into LDS at their CSR slot (u16 per product) and the
-//     rows are reduced out of LDS by the same code as the stream kernel
-//     above (deterministic order, same epilogue).  Rows longer than TBIN are
-//     cut into single-row bins whose partials go through spmv_long_fixup.
+//     tile-major as {value word or one-byte value code, col u16}, are streamed,
+//     multiplied against LDS, and
+//       light rows: each aligned group of 4 products is stored with one 16-byte
+//         store into the product array P at the entry's own stream position;
+//       heavy rows (>= 8 entries per tile on average): summed per (row, tile)
+//         inside the wave (segmented scan); one partial per run, no P traffic.
+//   phase 2  (persistent, wave-specialised: spmv_tiled_phase2s)
+//     per row bin of <= TBIN light products: loader waves gather the bin's
+//     (bin, tile) pieces from P (gsrc: where each group of 4 lies) and scatter
+//     them into an LDS image at their CSR slot (u16 per product); reducer waves
+//     sum the rows out of the previous image with the same code as the stream
+//     kernel above (deterministic order, same epilogue) and add up the heavy
+//     rows' partials.
 //
-// HBM bytes per entry: 4+2+1 read, 4 written (phase 1), 4+2 read (phase 2)
-// = 17 B vs the 8 B algorithmic, but all of it is streaming.
+// HBM bytes per light entry: 3 (coded) or 6 read + 4 written in phase 1,
+// 4 + 2 + 1 read in phase 2; per heavy entry 3.25 or 6.25 read -- against the
+// 8 B algorithmic, but all of it streamed.
 // ===========================================================================
 #ifndef SH_TCOLS
 #define SH_TCOLS 32768

@@ -3,11 +3,16 @@
 // What they compute is the per-row contract of every Lift strategy in the
 // reference (example/<algo>/kernel*.json:3, inventory in SURVEY.md 2.2):
 //   out[r] = epilogue( (+)_j ( x_or_identity(col_j) (x) val_j ), alpha, y[r], beta )
-// How they compute it is native: the matrix is streamed once, in CSR order,
-// with 16-byte-per-lane coalesced loads; no padded ELLPACK, no global temp
-// buffer, no re-reads.
+// How they compute it is native.  Two execution plans (chosen per matrix at
+// upload, engine.hip):
+//   A  "stream": x small enough for the per-XCD L2 (or a matrix with local
+//      columns): the matrix is streamed once, in CSR order, with
+//      16-byte-per-lane coalesced loads and x is gathered from global memory;
+//      no padded ELLPACK, no global temp buffer, no re-reads.  Described next.
+//   B  "x-tiled two-phase": big x with scattered columns: x tiles are staged in
+//      LDS and the products re-binned through HBM.  Described further down.
 //
-// Schedule (built on upload, engine.hip): the row range is cut into
+// Plan A schedule (built on upload): the row range is cut into
 //   * stream blocks: consecutive rows whose non-zeros (<= NNZ_BLK, counted
 //     from the 16-byte-aligned start) are staged as PRODUCTS in LDS by one
 //     256-thread workgroup and then reduced per row out of LDS by 1..64 lanes

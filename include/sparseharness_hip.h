@@ -124,8 +124,8 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
  * values=dict8(k): the matrix has k <= 256 distinct 4-byte values and the tiled stream carries
  * one-byte codes (lossless; SH_VALCODE=off keeps raw values); values=raw otherwise.
  * " tuned(stream=..ms,tiled=..ms)" is appended when the plan was confirmed by timing both at upload:
- * large matrices get the tiled plan by size, unless the CSR-stream plan runs > 10 % faster on the
- * device (matrices with local columns); SH_PLAN=stream|tiled or SH_AUTOTUNE=0 skip the timing. */
+ * large matrices get the tiled plan by size; when their columns are local (row bins touch less than
+ * half of the column tiles) both plans are timed and the CSR-stream plan is kept if > 10 % faster; SH_PLAN=stream|tiled or SH_AUTOTUNE=0 skip the timing. */
 int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen);
 
 /* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /

@@ -320,6 +320,7 @@ struct TiledHost {
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0, light_len = 0;
   int32_t n_partials = 0;
+  double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
 };
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
@@ -439,6 +440,11 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   }
   H.p_len = p_off;
   H.light_len = p_off;
+  {
+    int64_t pieces = 0;
+    for (const auto &v : bin_pieces) pieces += (int64_t)v.size();
+    H.tile_fill = (n_bins > 0) ? (double)pieces / ((double)n_bins * CT) : 1.0;
+  }
   // S2
   for (int t = 0; t < CT; t++) hrel[t] = light_total[t];
   H.heavy.resize((size_t)n_heavy);
@@ -746,8 +752,10 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
   {
     const char *forced = getenv("SH_PLAN");
     const char *tune = getenv("SH_AUTOTUNE");
+    // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
+    // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
     if (m->plan == PLAN_TILED && !(forced && (!strcmp(forced, "stream") || !strcmp(forced, "tiled"))) &&
-        !(tune && tune[0] == '0'))
+        !(tune && tune[0] == '0') && th.tile_fill < 0.5)
       autotune_plan(e, m);
   }
   *out = m;

@@ -112,3 +112,23 @@ def test_experiment_sweep_end_to_end(tmp_path):
     assert len(rows) == 4 * 4                                   # 3 raw trials + the median row per run
     assert {r_["matrix"] for r_ in rows} == {"matrix3", "matrix4"} and {r_["experiment_id"] for r_ in rows} == {"sweep1"}
     assert sum(r_["correct"] == "correct" for r_ in rows) == 12 and not any(r_["correct"] == "badvalues" for r_ in rows)
+
+
+def test_bench_script_emits_the_contract_line():
+    """bench.py at a reduced size: one JSON line with the driver's fields, roofline and cpu_baseline objects."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "300000", "--nnz", "6000000", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "GFLOP/s" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
+    assert d["parity"]["mismatches_rel_1e-5"] == 0 and d["value"] > 0

@@ -90,10 +90,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SpMV engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # SH_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path (sharding, barriers,
+    # max-over-ranks) on a one-GPU box; its timings mean nothing and the line says so
+    rehearsal = os.environ.get("SH_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     t_gen = time.time()
     rp, ci, va, n, desc = make_workload(args.workload, args.rows, args.nnz)
@@ -107,7 +114,7 @@ def main():
     s_rows, s_nnz = r1 - r0, int(s_rp[-1])
 
     stream = torch.cuda.current_stream()
-    eng = Engine(local_rank, stream=stream.cuda_stream)
+    eng = Engine(dev_index, stream=stream.cuda_stream)
     t_up = time.time()
     A = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va)
     t_up = time.time() - t_up
@@ -139,7 +146,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms_per_launch = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -239,6 +246,8 @@ def main():
         "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": A.describe()},
         "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,
     }
+    if rehearsal:
+        result["rehearsal"] = "all ranks shared GPU 0 over gloo: timings are not measurements"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -132,3 +132,26 @@ def test_bench_script_emits_the_contract_line():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
     assert d["parity"]["mismatches_rel_1e-5"] == 0 and d["value"] > 0
+
+
+def test_bench_script_two_ranks_rehearsal():
+    """The N > 1 path of bench.py (row sharding, barriers, max-over-ranks, rank-0 JSON) with two ranks sharing
+    GPU 0 over gloo (SH_BENCH_REHEARSAL=1); the driver runs the real thing, one rank per GPU over RCCL."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SH_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000",
+                        "--nnz", "8000000", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-1200:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["nnz"] == 8000000
+    assert 0 < d["roofline"]["rank_nnz"] < 8000000 and d["parity"]["mismatches_rel_1e-5"] == 0
+    assert d["cpu_baseline"] is None and "rehearsal" in d

@@ -4,6 +4,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <type_traits>
 
 #include "arithexpr_evaluator.h"
 #include "csv_utils.h"
@@ -21,7 +22,32 @@ static int failures = 0;
     if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } \
   } while (0)
 
+// `host_selftest --encode <matrix.mtx> <kernel.json>...`: load each kernel config and run
+// executorEncodeMatrix on the matrix (no GPU involved); one line per config.  tests/test_host.py
+// points it at the reference's own example/*/kernel*.json files to show that they are accepted as they are.
+template <typename T> static int encode_probe(const std::string &matrix, int n, char **jsons) {
+  SparseMatrix<T> m{matrix};
+  ConstXVectorGenerator<T> x((T)1);
+  ConstYVectorGenerator<T> y((T)0);
+  for (int i = 0; i < n; i++) {
+    KernelConfig<T> kc{std::string(jsons[i])};
+    auto args = executorEncodeMatrix(1ul << 30, kc, m, (T)0, x, y, (T)1, (T)0);
+    const std::string &src = kc.getSource();
+    const char *sr = std::is_integral<T>::value
+                         ? ((src.find("int_max") != std::string::npos || src.find("doubleMinMax") != std::string::npos) ? "max-min" : "or-and")
+                         : ((src.find("clmin") != std::string::npos || src.find("absadd") != std::string::npos) ? "min-plus" : "plus-times");
+    std::printf("ENCODE %s name=%s semiring=%s rows=%d cols=%d size_args=", jsons[i], kc.getName().c_str(), sr, args.rows, args.cols);
+    for (unsigned v : args.size_args) std::printf("%u,", v);
+    std::printf(" output=%u temp_globals=%zu temp_locals=%zu x=%zu idxs=%zu\n", args.output, args.temp_globals.size(),
+                args.temp_locals.size(), args.x_vect.size(), args.m_idxs.size());
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 4 && (std::string(argv[1]) == "--encode" || std::string(argv[1]) == "--encode-int"))
+    return std::string(argv[1]) == "--encode" ? encode_probe<float>(argv[2], argc - 3, argv + 3)
+                                              : encode_probe<int>(argv[2], argc - 3, argv + 3);
   const std::string dir = argc > 1 ? argv[1] : ".";
   // ---- run-file: 6 fields, trailing comma tolerated, stop at first blank line (inc/csv_utils.h:16-49, src/run.cpp:4-16)
   {

@@ -1,5 +1,6 @@
 """Host-side logic of the product (no GPU): the C++ mirror's MatrixMarket loader,
 kernel-config/run-file/CLI surface, the in-harness gold, and the generators."""
+import glob
 import json
 import os
 import subprocess
@@ -263,3 +264,35 @@ def test_binary_csr_cache_roundtrip_and_invalidation(tmp_path, monkeypatch):
     # PageRank (needs file order) never goes through the cache
     pr = H.mm_load(mtx("matrix3"), normalise=H.NORM_PAGERANK)
     assert pr[0] == 20
+
+
+REF_EXAMPLE = os.path.join(os.environ.get("SH_REFERENCE", "/root/reference"), "example")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLE), reason="reference tree not present (GPU box)")
+def test_reference_kernel_configs_are_accepted_unmodified():
+    """The reference's own example/<algo>/kernel*.json (7 Lift strategies x 5 apps) load into KernelConfig and
+    drive executorEncodeMatrix with the reference's size rules: MHeight padding A-6, MWidthC = cl_width/splitSize
+    or cols for ragged layouts (inc/kernel_utils.h:57-65); the OpenCL source only serves as the semiring hint."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "selftest"], stderr=subprocess.DEVNULL)
+    exe = os.path.join(HOST, "bin", "host_selftest")
+    want_sr = {"spmv": "plus-times", "pr": "plus-times", "sssp": "min-plus", "bfs": "or-and", "scc": "max-min"}
+    for algo, sr in want_sr.items():
+        files = sorted(glob.glob(os.path.join(REF_EXAMPLE, algo, "kernel*.json")))
+        assert len(files) == 7, algo
+        mode = "--encode-int" if algo in ("bfs", "scc") else "--encode"
+        r = subprocess.run([exe, mode, mtx("matrix3"), *files], capture_output=True, text=True, timeout=120,
+                           env={k: v for k, v in os.environ.items() if k != "SH_QUIET_TIMERS"})
+        assert r.returncode == 0, r.stderr[-500:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("ENCODE ")]
+        assert len(lines) == 7
+        by_name = {}
+        for l in lines:
+            f = dict(kv.split("=", 1) for kv in l.split()[2:])
+            assert f["semiring"] == sr, l
+            by_name[f["name"]] = f
+        # matrix3: 20 rows, longest row 9 (tests/golden): the reference's size rules
+        assert by_name["glb-sdp"]["size_args"] == "20,9,20," and by_name["glb-sdp"]["output"] == "80"
+        assert by_name["swrg-slcl-sdp-chunk-128"]["rows"] == "128"                 # 20 + (128 - 20 % 128), quirk A-6
+        assert by_name["awrg-alcl-fdp-chunk-rsa-8"]["size_args"] == "24,20,"         # ragged: MWidthC = cols
+        assert by_name["awrg-alcl-alcl-edp-split-8"]["size_args"] == "20,2,20,"      # (9 + (8 - 9 % 8)) / 8

@@ -533,3 +533,27 @@ def test_random_shapes_match_oracle_bit_for_bit(eng):
         np.testing.assert_array_equal(got, O.kernel(O.MAX_MIN_I32, rp, ci, vi - 5, xi - 2, yi, 7, -3, vlength=cols))
 
     check()
+
+
+def test_config4_rmat23_sssp_and_bfs_to_convergence(eng, plan):
+    """BASELINE.json config 4 at full size: (min,+) SSSP and (or,and) BFS on R-MAT scale 23 (134 M entries) run to
+    convergence on the device and are compared bit for bit -- vector and launch count -- with the CPU oracle."""
+    import os
+    if plan != "tiled" or os.environ.get("SH_VALCODE") == "off":
+        pytest.skip("full size once, under the layout the engine picks for it")
+    rp, ci, va = H.rmat(23)
+    n = 1 << 23
+    for sr, a, b in ((O.MIN_PLUS_F32, 0.0, 0.0), (O.OR_AND_I32, 1, 0)):
+        dt = O.elem_dtype(sr)
+        vals = va.astype(dt)
+        x0 = O.initial_vector(sr, n)
+        want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 200)
+        A = eng.upload_csr(n, n, rp, ci, vals)
+        assert A.plan()[0] == "tiled"
+        xv, yv, sc = eng.vector(x0), eng.vector(x0), eng.alloc(n)
+        iters, conv, per, total = eng.iterate(sr, A, xv, yv, sc, a, b, 1e-4, 200)
+        assert (iters, conv) == (w_it, w_conv) and conv
+        np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
+        for v in (xv, yv, sc):
+            v.free()
+        A.free()

@@ -34,8 +34,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 
 # HBM bytes per SpMV launch measured in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
 # WRITE_SIZE, MI355X_MICROARCH.md "HBM"); PMC cannot be collected inside this process.  Keyed by
-# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_v5_powerlaw.txt
-MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 2430943642}
+# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_v6_powerlaw.txt
+MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 2328464384}
 
 WORKLOADS = {
     # name: (kind, rows, nnz, description)
@@ -193,7 +193,7 @@ def main():
     # ---- transparency leg (N=1): the same matrix without the one-byte value coding, i.e. the layout a
     # matrix with more than 256 distinct values gets; NOT the reported value
     ablation = None
-    if rank == 0 and world == 1 and not args.no_ablation and "values=dict8" in A.describe():
+    if rank == 0 and world == 1 and not args.no_ablation and "values=dict" in A.describe():
         prev_vc = os.environ.get("SH_VALCODE")
         os.environ["SH_VALCODE"] = "off"
         try:
@@ -235,7 +235,7 @@ def main():
                      "traffic": (args.traffic_bytes if args.traffic_bytes is not None else
                                  (None if (args.rows or args.nnz) else
                                   MEASURED_TRAFFIC_BYTES.get((args.workload, A.plan()[0], world)))),
-                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_v5_powerlaw.txt",
+                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_v6_powerlaw.txt",
                      "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)" if A.plan()[0] == "tiled"
                                 else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),

@@ -62,6 +62,7 @@ struct sh_csr {
   uint8_t *d_tcode = nullptr;    // value coding: one-byte dictionary codes instead of d_tval
   uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
   int n_vdict = 0;               // 0 = values stored raw
+  int code_bits = 0;             // 8 or 4 when n_vdict != 0
   int n_vdict_used = 0;          // distinct values found (<= VDICT)
   uint16_t *d_tcol = nullptr, *d_pslot = nullptr;
   LongRow *d_tlong = nullptr;   // heavy rows (pre-reduced in phase 1)
@@ -317,6 +318,7 @@ struct TiledHost {
   std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
   std::vector<uint32_t> vdict;       // empty = raw values
   int vdict_used = 0;
+  int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values)
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0, light_len = 0;
   int32_t n_partials = 0;
@@ -473,8 +475,10 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
     return false; // padding would cost more than 25 %: keep the stream plan
 
-  // P3: value dictionary: <= VDICT distinct bit patterns (code 0 = the all-zero word, used by padding)
-  // => the stream carries one-byte codes.  SH_VALCODE=off keeps raw values.
+  // P3: value dictionary: <= VDICT distinct bit patterns => the stream carries one-byte codes, <= 16 => four-bit
+  // codes.  Code 0 is the all-zero word (padding) unless exactly 16 finite non-zero values fill the four-bit table,
+  // in which case padding borrows code 0's value: its products are identity (x) finite == identity.
+  // SH_VALCODE=off keeps raw values, SH_VALCODE=8 never packs nibbles.
   ValSet dict;
   {
     const char *vc = getenv("SH_VALCODE");
@@ -486,18 +490,34 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         const int64_t e = std::min<int64_t>(nnz, (blk + 1) * 65536);
         for (int64_t j = blk * 65536; j < e && !vs.overflow; j++) vs.add(val[j]);
       });
-      dict.add(0u);
+      // the distinct words of the data, in ascending bit-pattern order (the same dictionary whatever the
+      // thread count)
+      ValSet all;
       for (const ValSet &vs : part) {
-        if (vs.overflow) dict.overflow = true;
-        for (uint32_t b : vs.list) dict.add(b);
+        if (vs.overflow) all.overflow = true;
+        for (uint32_t b : vs.list) all.add(b);
       }
-      // codes in ascending bit-pattern order: the same dictionary whatever the thread count
-      if (!dict.overflow) {
-        std::vector<uint32_t> sorted(dict.list);
-        std::sort(sorted.begin(), sorted.end());
-        ValSet ordered;
-        for (uint32_t b : sorted) ordered.add(b);
-        dict = ordered;
+      std::vector<uint32_t> words(all.list);
+      std::sort(words.begin(), words.end());
+      const bool has_zero = !words.empty() && words[0] == 0u;
+      bool all_finite = true;   // as floats: padding may then carry ANY code (identity (x) finite == identity in all four semirings)
+      for (uint32_t b : words) all_finite = all_finite && ((b >> 23) & 0xFFu) != 0xFFu;
+      dict = ValSet();
+      if (all.overflow || words.size() > (size_t)VDICT) {
+        dict.overflow = true;
+      } else if (!(vc && !strcmp(vc, "8")) && words.size() + (has_zero ? 0 : 1) <= 16) {
+        H.code_bits = 4;
+        dict.add(0u);                      // code 0 = the all-zero word: padding
+        for (uint32_t b : words) dict.add(b);
+      } else if (!(vc && !strcmp(vc, "8")) && words.size() == 16 && all_finite) {
+        H.code_bits = 4;                   // 16 finite values and no zero among them: padding borrows code 0's value
+        for (uint32_t b : words) dict.add(b);
+      } else if (words.size() + (has_zero ? 0 : 1) <= (size_t)VDICT) {
+        H.code_bits = 8;
+        dict.add(0u);
+        for (uint32_t b : words) dict.add(b);
+      } else {
+        dict.overflow = true;
       }
       coded = !dict.overflow;
     }
@@ -506,7 +526,11 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   const bool coded = !H.vdict.empty();
 
   // P4 / P5: fill
-  if (coded) { H.vdict_used = (int)H.vdict.size(); H.tcode.assign((size_t)H.stream_len, 0); H.vdict.resize(VDICT, 0u); }
+  if (coded) {
+    H.vdict_used = (int)H.vdict.size();
+    H.tcode.assign((size_t)(H.code_bits == 4 ? H.stream_len / 2 : H.stream_len), 0);
+    H.vdict.resize(VDICT, 0u);
+  }
   else H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)H.stream_len / 4, 0u);
@@ -515,7 +539,11 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
     const bool in_range = (uint32_t)c < (uint32_t)cols;
-    if (coded) H.tcode[(size_t)pos] = (uint8_t)dict.code[dict.find(val[j])];
+    if (coded) {
+      const uint32_t code = dict.code[dict.find(val[j])];
+      if (H.code_bits == 4) H.tcode[(size_t)pos >> 1] |= (uint8_t)(code << ((pos & 1) * 4));   // both nibbles of a byte belong to one group, one thread
+      else H.tcode[(size_t)pos] = (uint8_t)code;
+    }
     else H.tval[(size_t)pos] = val[j];
     H.tcol[(size_t)pos] = in_range ? (uint16_t)(c % TCOLS) : TCOL_IDENTITY;
   };
@@ -722,6 +750,7 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     if (!th.vdict.empty()) {
       m->n_vdict = (int)th.vdict.size();
       m->n_vdict_used = th.vdict_used;
+      m->code_bits = th.code_bits;
       HIP_TRY_M(hipMalloc((void **)&m->d_tcode, th.tcode.size() + 64));
       HIP_TRY_M(hipMemcpyAsync(m->d_tcode, th.tcode.data(), th.tcode.size(), hipMemcpyHostToDevice, e->stream));
       HIP_TRY_M(hipMalloc((void **)&m->d_vdict, th.vdict.size() * 4));
@@ -808,7 +837,7 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
   if (streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
-                          ? (m->n_vdict ? 3ull : 6ull) * m->stream_len + (uint64_t)(m->stream_len - m->light_len) /* gdest */ +
+                          ? (m->n_vdict ? 2ull : 6ull) * m->stream_len + (m->n_vdict ? (uint64_t)m->stream_len * m->code_bits / 8 : 0ull) + (uint64_t)(m->stream_len - m->light_len) /* gdest */ +
                                 4ull * m->light_len /* P written */ + 7ull * m->light_len /* phase 2: P, slot, gsrc */ +
                                 vec /* x once: a tile is re-staged per phase-1 workgroup, but out of its XCD's L2 */
                           : 8ull * m->nnz + vec;
@@ -821,7 +850,7 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     return SH_EINVAL;
   if (m->plan == PLAN_TILED) {
     char vals[32];
-    if (m->n_vdict) snprintf(vals, sizeof vals, "dict8(%d)", m->n_vdict_used);
+    if (m->n_vdict) snprintf(vals, sizeof vals, "dict%d(%d)", m->code_bits, m->n_vdict_used);
     else snprintf(vals, sizeof vals, "raw");
     snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM", vals,
              (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
@@ -941,12 +970,16 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
   if (A->plan == PLAN_TILED) {
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
-    if (A->n_vdict)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, true>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+    if (A->n_vdict && A->code_bits == 4)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+                         A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
+                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
+    else if (A->n_vdict)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                          A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, false>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
                          A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
                          (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
     HIP_TRY(e, hipGetLastError());

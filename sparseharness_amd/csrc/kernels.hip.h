@@ -464,7 +464,8 @@ struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, pslot, pad; };
 constexpr int P1U_VC = SH_P1_UNROLL_VC;
 constexpr int VDICT = 256;
 
-template <class SR, bool VC>
+// VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
+template <class SR, int VC>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
@@ -472,7 +473,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     uint32_t *__restrict__ P, uint32_t *__restrict__ partial) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
-  using VWord = typename std::conditional<VC, uint32_t, uint4>::type;   // 4 codes or 4 values
+  // the value words of one group of 4 entries: 4 values, 4 one-byte codes, or 4 nibbles
+  using VWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint32_t, uint16_t>::type>::type;
   // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
 #ifndef SH_XS_EXTRA
 #define SH_XS_EXTRA 0
@@ -512,8 +514,10 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   // the four products of one 16-byte group: x gathered from LDS, values decoded when coded
   auto products = [&](const VWord &w, const uint2 &c, T (&pr)[4]) {
     uint4 v;
-    if constexpr (VC)
+    if constexpr (VC == 1)
       v = make_uint4(ds[w & 0xFFu], ds[(w >> 8) & 0xFFu], ds[(w >> 16) & 0xFFu], ds[w >> 24]);
+    else if constexpr (VC == 2)
+      v = make_uint4(ds[w & 0xFu], ds[(w >> 4) & 0xFu], ds[(w >> 8) & 0xFu], ds[(w >> 12) & 0xFu]);
     else
       v = w;
     pr[0] = SR::mul(from_bits<T>(xs[c.x & 0xFFFFu]), from_bits<T>(v.x));

@@ -27,12 +27,13 @@ def eng():
     e.close()
 
 
-@pytest.fixture(params=["stream", "tiled", "tiled-raw"], autouse=True)
+@pytest.fixture(params=["stream", "tiled", "tiled-8bit", "tiled-raw"], autouse=True)
 def plan(request, monkeypatch):
-    """Every parity test runs under both execution plans of the engine; the tiled plan with its
-    one-byte value coding (taken whenever the matrix has <= 256 distinct values) and without."""
+    """Every parity test runs under both execution plans of the engine; the tiled plan with its value
+    coding as the data allows (four-bit codes for <= 16 values, one-byte codes for <= 256), with one-byte
+    codes at most, and with raw values."""
     monkeypatch.setenv("SH_PLAN", request.param.split("-")[0])
-    monkeypatch.setenv("SH_VALCODE", "off" if request.param.endswith("raw") else "auto")
+    monkeypatch.setenv("SH_VALCODE", {"raw": "off", "8bit": "8"}.get(request.param.split("-")[-1], "auto"))
     return request.param.split("-")[0]
 
 
@@ -268,7 +269,12 @@ def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
     monkeypatch.setenv("SH_VALCODE", "auto")
     rp, ci, va, n = cases["powerlaw_int"]
     A = eng.upload_csr(n, n, rp, ci, va)
-    assert "values=dict8(17)" in A.describe()        # weights 1..16 plus the padding word 0
+    assert "values=dict4(16)" in A.describe()        # weights 1..16: four-bit codes, padding borrows code 0's value
+    A.free()
+    monkeypatch.setenv("SH_VALCODE", "8")
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert "values=dict8(17)" in A.describe()        # one-byte codes: the 16 weights plus the padding word 0
+    monkeypatch.setenv("SH_VALCODE", "auto")
     A.free()
     rp, ci, va, n = cases["powerlaw_real"]
     A = eng.upload_csr(n, n, rp, ci, va)
@@ -294,6 +300,44 @@ def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
         np.testing.assert_array_equal(out.download(np.int32),
                                       O.kernel(O.OR_AND_I32, rp, ci, vals.view(np.int32), x, x, 1, 0))
         for v in (xv, out):
+            v.free()
+        A.free()
+    # four-bit codes: <= 16 words counting a zero; exactly 16 non-zero words only if all are finite (padding then
+    # borrows code 0's value, which an inf or NaN would turn into a NaN product)
+    small = np.unique(rng.integers(1, 2**30, 64).astype(np.uint32))[:16]
+    cases4 = ((small[:15], "dict4(16)"), (small, "dict4(16)"), (np.concatenate([[0], small[:15]]).astype(np.uint32), "dict4(16)"),
+              (np.concatenate([small[:15], [0x7F800000]]).astype(np.uint32), "dict8(17)"), (small[:1], "dict4(2)"))
+    for words, want in cases4:
+        vals = words[rng.integers(0, len(words), nnz)]
+        vals[:len(words)] = words
+        A = eng.upload_csr(m, m, rp, ci, vals.view(np.float32))
+        assert f"values={want}" in A.describe(), (A.describe(), want)
+        x = rng.integers(0, 2, m).astype(np.int32)
+        xv, out = eng.vector(x), eng.alloc(m).fill(0)
+        eng.spmv(O.OR_AND_I32, A, xv, None, 1, 0, out)
+        np.testing.assert_array_equal(out.download(np.int32),
+                                      O.kernel(O.OR_AND_I32, rp, ci, vals.view(np.int32), x, x, 1, 0))
+        for v in (xv, out):
+            v.free()
+        A.free()
+    # (+,x) and (min,+) with a FULL four-bit table (weights 1..16, negative ones too): the borrowed padding value
+    # must leave every sum untouched, heavy rows included
+    deg = rng.multinomial(nnz - 30_000, np.ones(m) / m)
+    deg[5] += 30_000                                     # a heavy row: its padded groups are summed in phase 1
+    rp2 = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    for sign in (1.0, -1.0):
+        fv = (sign * rng.integers(1, 17, nnz)).astype(np.float32)
+        xf = rng.integers(0, 3, m).astype(np.float32)
+        A = eng.upload_csr(m, m, rp2, ci, fv)
+        assert "values=dict4(16)" in A.describe()
+        xv, out = eng.vector(xf), eng.alloc(m).fill(0)
+        eng.spmv(O.PLUS_TIMES_F32, A, xv, None, 1.0, 0.0, out)
+        np.testing.assert_array_equal(bits(out.download(np.float32)), bits(O.gold_dot(rp2, ci, fv, xf)))
+        x0 = O.initial_vector(O.MIN_PLUS_F32, m)
+        xv2 = eng.vector(x0)
+        eng.spmv(O.MIN_PLUS_F32, A, xv2, xv2, 0.0, 0.0, out)
+        np.testing.assert_array_equal(bits(out.download(np.float32)), bits(O.kernel(O.MIN_PLUS_F32, rp2, ci, fv, x0, x0, 0.0, 0.0)))
+        for v in (xv, xv2, out):
             v.free()
         A.free()
 
@@ -539,7 +583,7 @@ def test_config4_rmat23_sssp_and_bfs_to_convergence(eng, plan):
     """BASELINE.json config 4 at full size: (min,+) SSSP and (or,and) BFS on R-MAT scale 23 (134 M entries) run to
     convergence on the device and are compared bit for bit -- vector and launch count -- with the CPU oracle."""
     import os
-    if plan != "tiled" or os.environ.get("SH_VALCODE") == "off":
+    if plan != "tiled" or os.environ.get("SH_VALCODE") != "auto":
         pytest.skip("full size once, under the layout the engine picks for it")
     rp, ci, va = H.rmat(23)
     n = 1 << 23

@@ -117,12 +117,13 @@ int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
  * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM).
  * streamed_bytes = HBM bytes one SpMV moves by construction under that plan (tiled: 3 or 6 B per
  * stream entry + 4 B written and 7 B re-read per light entry + the vectors; measured on the
- * headline matrix: 2.43 GB against 2.32 GB by this count). */
+ * headline matrix: 2.33 GB against 2.22 GB by this count). */
 int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
 /* One-line description of the layout built at upload, for logs and bench records, e.g.
- * "tiled values=dict8(16) tiles=306 chunks=6416 bins=8532 heavy_rows=5276 stream=200.9M light=138.3M".
- * values=dict8(k): the matrix has k <= 256 distinct 4-byte values and the tiled stream carries
- * one-byte codes (lossless; SH_VALCODE=off keeps raw values); values=raw otherwise.
+ * "tiled values=dict4(16) tiles=306 chunks=6552 bins=8738 heavy_rows=5276 stream=206.4M light=137.9M".
+ * values=dict8(k) / dict4(k): the matrix has k <= 256 / <= 16 distinct 4-byte values and the tiled stream
+ * carries one-byte / four-bit codes (lossless; SH_VALCODE=8 stops at one-byte codes, SH_VALCODE=off keeps
+ * raw values); values=raw otherwise.
  * " tuned(stream=..ms,tiled=..ms)" is appended when the plan was confirmed by timing both at upload:
  * large matrices get the tiled plan by size; when their columns are local (row bins touch less than
  * half of the column tiles) both plans are timed and the CSR-stream plan is kept if > 10 % faster; SH_PLAN=stream|tiled or SH_AUTOTUNE=0 skip the timing. */

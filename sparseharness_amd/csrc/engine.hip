@@ -28,12 +28,9 @@ struct sh_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // side stream for the heavy-row fixup of the tiled plan (runs beside phase 2; both only need phase 1)
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t *d_flags = nullptr;   // per-iteration convergence flags
   int32_t n_flags = 0;
-  int32_t *h_flag = nullptr;    // pinned
+  int32_t *h_flag = nullptr;    // pinned, 64 B: [0] convergence flag read-back, [8] give-up word of the fused launch
   char name[256] = {0};
   int n_cus = 256;
   std::string err;
@@ -71,6 +68,17 @@ struct sh_csr {
   int32_t *d_lrp = nullptr;     // light row offsets, bit 31 = heavy row
   int64_t light_len = 0;
   int64_t stream_len = 0, p_len = 0;
+  // slabs of the tiled plan (host copies: launch geometry)
+  std::vector<int32_t> slab_bin0, slab_chunk0;
+  int64_t slab_cap = 0, p_alloc = 0;   // products per ring slot / in P
+  int32_t ring = 1;
+  // fused launch (spmv_tiled_fused): work queues, per-slab needs, control block
+  bool fused = false;
+  int32_t n2 = 0;               // phase-2 workers per XCD slot
+  TileChunk *d_qchunks = nullptr, *d_hchunks = nullptr;
+  int32_t *d_lq0 = nullptr, *d_need = nullptr;
+  uint32_t *d_ctl = nullptr;
+  int32_t n_hchunks = 0, ctl_words = 0;
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
 
@@ -154,6 +162,16 @@ struct ValSet {
   }
 };
 
+// After a stream synchronisation: did a fused launch give up on a hand-off (bounded spins, kernels.hip.h)?
+static int check_gave_up(sh_engine *e) {
+  if (e->h_flag && e->h_flag[8]) {
+    e->h_flag[8] = 0;
+    return fail(e, SH_EHIP, "a fused SpMV launch gave up waiting for a slab hand-off (not all workgroups resident? "
+                            "another kernel sharing the GPU?): results are invalid; SH_FUSED=0 uses separate launches");
+  }
+  return SH_OK;
+}
+
 extern "C" {
 
 int sh_abi_version(void) { return SH_ABI_VERSION; }
@@ -194,10 +212,8 @@ static int engine_create(int device, void *stream, bool borrow, sh_engine **out)
   }
   if (r == hipSuccess) r = hipEventCreate(&e->ev0);
   if (r == hipSuccess) r = hipEventCreate(&e->ev1);
-  if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking);
-  if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-  if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   if (r == hipSuccess) r = hipHostMalloc((void **)&e->h_flag, 64, hipHostMallocDefault);
+  if (r == hipSuccess) memset(e->h_flag, 0, 64);
   hipDeviceProp_t prop;
   if (r == hipSuccess) r = hipGetDeviceProperties(&prop, device);
   if (r != hipSuccess) {
@@ -227,9 +243,6 @@ int sh_engine_destroy(sh_engine *e) {
   if (e->h_flag) (void)hipHostFree(e->h_flag);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
-  if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return SH_OK;
@@ -256,7 +269,7 @@ int sh_engine_synchronize(sh_engine *e) {
   if (!e)
     return SH_EINVAL;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return SH_OK;
+  return check_gave_up(e);
 }
 
 // ---------------------------------------------------------------- matrix
@@ -322,6 +335,16 @@ struct TiledHost {
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0, light_len = 0;
   int32_t n_partials = 0;
+  // slabs: runs of consecutive bins whose products share one slot of the P ring
+  std::vector<int32_t> slab_bin0;    // [n_slabs + 1] first bin of each slab
+  std::vector<int32_t> slab_chunk0;  // [n_slabs + 2] first phase-1 chunk of each slab; the last range holds the heavy chunks
+  int64_t slab_cap = 0;              // products per ring slot
+  int32_t ring = 1;                  // ring slots (>= n_slabs: every slab has addresses of its own)
+  // the fused launch's work queues: light chunks per XCD slot (slab-major, no fillers), heavy chunks,
+  // and per slab {light chunks, bins}
+  std::vector<TileChunk> qchunks, hchunks;
+  int32_t lq0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> need;
   double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
 };
 
@@ -361,7 +384,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       r1++;
     RowBin b{};
     b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = (int32_t)light_off(r);
-    b.cnt = (int32_t)(light_off(r1) - light_off(r)); b.pslot = -1;
+    b.cnt = (int32_t)(light_off(r1) - light_off(r));
     H.bins.push_back(b);
     r = r1;
   }
@@ -426,20 +449,50 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     const int64_t r = heavy_rows_idx[(size_t)hi];
     collect(scratch[(size_t)th], r, r + 1, true, heavy_pieces[(size_t)hi]);
   });
-  // S1 (positions are relative to the tile start until the tile starts are known)
-  std::vector<int64_t> light_total(CT, 0), hrel(CT, 0);
-  int64_t p_off = 0;
-  for (int64_t bi = 0; bi < n_bins; bi++) {
-    RowBin &b = H.bins[(size_t)bi];
-    if (b.n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
-    if (p_off + b.n > INT32_MAX) return false;
-    b.pstart = (int32_t)p_off;
-    p_off += b.n;
-    for (Piece &pc : bin_pieces[(size_t)bi]) {
-      pc.pos = light_total[(size_t)pc.tile];
-      light_total[(size_t)pc.tile] += (pc.cnt + 3) & ~3;
+  // Slabs: consecutive bins up to slab_cap products.  The stream is slab-major -- [slab 0: tile 0's
+  // pieces of the slab's bins, tile 1's, ...][slab 1: ...]...[heavy pieces, tile-major] -- so that phase 2 of
+  // a slab can run right behind phase 1 of the same slab and P only ever holds `ring` slabs: a
+  // product is re-read (and its line overwritten by a later slab) while it is still in the 256 MiB
+  // Infinity Cache (profiles/r02_lab_slab_mall_ring_microbench.log: the same bytes move at 7.9 instead
+  // of 5.3 TB/s).  P position of a light entry = its stream position + the slab's pdelta.
+  {
+    // default: one slab, P linear (two launches).  SH_SLAB_MB / SH_RING cut slabs and reuse P slots: that is
+    // what the fused launch (SH_FUSED=1) is built around.
+    double cap_mb = 1e9;
+    if (const char *e = getenv("SH_SLAB_MB")) cap_mb = atof(e);
+    H.slab_cap = std::max<int64_t>(TBIN, (int64_t)std::min(cap_mb * 262144.0, 2e9)) & ~int64_t(3);
+    H.ring = 3;
+    if (const char *e = getenv("SH_RING")) H.ring = std::max(1, atoi(e));
+    int64_t acc = 0;
+    H.slab_bin0.push_back(0);
+    for (int64_t bi = 0; bi < n_bins; bi++) {
+      const int64_t n = H.bins[(size_t)bi].n;
+      if (n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
+      if (acc > 0 && acc + n > H.slab_cap) { H.slab_bin0.push_back((int32_t)bi); acc = 0; }
+      acc += n;
     }
+    H.slab_bin0.push_back((int32_t)n_bins);
   }
+  const int64_t n_slabs = (int64_t)H.slab_bin0.size() - 1;
+  if (n_slabs <= H.ring) H.ring = (int32_t)std::max<int64_t>(1, n_slabs);   // linear: no slot is reused
+  // S1: positions are relative to the (slab, tile) run until the run starts are known
+  std::vector<int64_t> run_len((size_t)(n_slabs * CT), 0), run_start((size_t)(n_slabs * CT), 0), hrel(CT, 0);
+  std::vector<int32_t> slab_of_bin((size_t)n_bins, 0);
+  int64_t p_off = 0;
+  for (int64_t sl = 0; sl < n_slabs; sl++)
+    for (int64_t bi = H.slab_bin0[(size_t)sl]; bi < H.slab_bin0[(size_t)sl + 1]; bi++) {
+      RowBin &b = H.bins[(size_t)bi];
+      slab_of_bin[(size_t)bi] = (int32_t)sl;
+      b.slab = (int32_t)sl;
+      if (p_off + b.n > INT32_MAX) return false;
+      b.pstart = (int32_t)p_off;
+      p_off += b.n;
+      for (Piece &pc : bin_pieces[(size_t)bi]) {
+        int64_t &rl = run_len[(size_t)(sl * CT + pc.tile)];
+        pc.pos = rl;
+        rl += (pc.cnt + 3) & ~3;
+      }
+    }
   H.p_len = p_off;
   H.light_len = p_off;
   {
@@ -447,8 +500,18 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (const auto &v : bin_pieces) pieces += (int64_t)v.size();
     H.tile_fill = (n_bins > 0) ? (double)pieces / ((double)n_bins * CT) : 1.0;
   }
-  // S2
-  for (int t = 0; t < CT; t++) hrel[t] = light_total[t];
+  std::vector<int64_t> slab_start((size_t)n_slabs + 1, 0), pdelta((size_t)n_slabs, 0);
+  {
+    int64_t pos = 0;
+    for (int64_t sl = 0; sl < n_slabs; sl++) {
+      slab_start[(size_t)sl] = pos;
+      for (int t = 0; t < CT; t++) { run_start[(size_t)(sl * CT + t)] = pos; pos += run_len[(size_t)(sl * CT + t)]; }
+      pdelta[(size_t)sl] = (sl % H.ring) * H.slab_cap - slab_start[(size_t)sl];
+      if (H.ring >= n_slabs) pdelta[(size_t)sl] = 0;   // linear layout: P position == stream position
+    }
+    slab_start[(size_t)n_slabs] = pos;   // == light_len
+  }
+  // S2: heavy pieces; positions relative to the tile's heavy run
   H.heavy.resize((size_t)n_heavy);
   {
     int64_t slots = 0;
@@ -463,13 +526,13 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       }
       H.heavy[(size_t)hi] = LongRow{(int32_t)heavy_rows_idx[(size_t)hi], (int32_t)slots, np, 0};
       slots += np;
-      if (slots > 0x7FFFFFF0ll) return false;
+      if (slots > (int64_t)GD_SLOT_MASK) return false;   // the slot shares its gdest word with the scan hints
     }
     H.n_partials = (int32_t)slots;
   }
-  int64_t total = 0;
-  std::vector<int64_t> tile_start(CT, 0), heavy_start(CT, 0);
-  for (int t = 0; t < CT; t++) { tile_start[t] = total; heavy_start[t] = total + light_total[t]; total += hrel[t]; }   // hrel = light + heavy
+  int64_t total = H.light_len;
+  std::vector<int64_t> heavy_start(CT, 0);
+  for (int t = 0; t < CT; t++) { heavy_start[t] = total; total += hrel[t]; }
   if (total > INT32_MAX - 8) return false;
   H.stream_len = total;
   if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
@@ -553,9 +616,10 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     int64_t off = b.pstart;
     for (const Piece &pc : bin_pieces[(size_t)bi]) {
       const int32_t padded = (pc.cnt + 3) & ~3;
-      const int64_t spos = tile_start[(size_t)pc.tile] + pc.pos;
+      const int64_t sl = slab_of_bin[(size_t)bi];
+      const int64_t spos = run_start[(size_t)(sl * CT + pc.tile)] + pc.pos;
       for (int32_t q = 0; q < padded; q += 4)
-        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(spos + q);
+        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(spos + q + pdelta[(size_t)sl]);   // where the group lies in the P ring
       sc.pos[(size_t)pc.tile] = spos;        // next free stream position of this (bin, tile) piece
       sc.count[(size_t)pc.tile] = (int32_t)(off - spos);   // P position = stream position + this (fits: both < 2^31)
       off += padded;
@@ -578,41 +642,106 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     Scratch &sc = scratch[(size_t)th];
     for (const Piece &pc : heavy_pieces[(size_t)hi]) {
       const int32_t padded = (pc.cnt + 3) & ~3;
-      const int64_t spos = tile_start[(size_t)pc.tile] + pc.pos;
+      const int64_t spos = heavy_start[(size_t)pc.tile] + pc.pos;
       int32_t part = lr.slot0 + pc.part0;
+      int64_t part_q0 = 0;                                         // where (in q) the current partial starts
       for (int32_t q = 0; q < padded; q += 4) {
-        const int64_t grel = (pc.pos + q) / 4;                     // group index inside the tile
-        if (q > 0 && grel % 64 == 0) part++;                       // next wave of phase 1
-        H.gdest[(size_t)(spos + q) / 4] = (uint32_t)part;          // partial slot of this group
+        const int64_t grel = (pc.pos + q) / 4;                     // group index inside the tile's heavy run
+        if (q > 0 && grel % 64 == 0) { part++; part_q0 = q; }      // next wave of phase 1
+        const bool last = q + 4 >= padded || (grel + 1) % 64 == 0;
+        // partial slot of this group, groups of the same partial to its left, end-of-partial mark
+        H.gdest[(size_t)(spos + q) / 4] = (uint32_t)part | ((uint32_t)((q - part_q0) / 4) << GD_DIST_SHIFT) | (last ? GD_LAST : 0u);
       }
       sc.pos[(size_t)pc.tile] = spos;
     }
     for (int32_t j = rp[r]; j < rp[r + 1]; j++)
       put_entry(sc.pos[(size_t)tile_of(ci[j])]++, j);
   });
-  // 4. phase-1 work items.  Cuts are multiples of 64 groups from the tile start (so wave
-  //    boundaries are the ones assumed above).  Order: workgroups are dealt round-robin over
-  //    the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a
-  //    chunk of a tile with tile % 8 == p % 8: every XCD then stages only its own eighth of x
-  //    through its L2 instead of all of it (speed only; correctness does not depend on placement).
+  // 4. phase-1 work items: <= TCHUNK entries of one (slab, tile) run, or of one tile's heavy run
+  //    (cuts are multiples of 64 groups from the run start, so wave boundaries are the ones assumed
+  //    above).  Order: slab-major; inside a slab workgroups are dealt round-robin over the 8 XCDs
+  //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
+  //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
+  //    of all of it (speed only; correctness does not depend on placement).
   int64_t chunk = TCHUNK;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
   if (const char *e = getenv("SH_CHUNK")) chunk = std::max(1024, atoi(e)) & ~255;   // tuning knob
   const bool xcd_order = !(getenv("SH_XCD_ORDER") && getenv("SH_XCD_ORDER")[0] == '0');
-  std::vector<TileChunk> per_xcd[8];
-  for (int t = 0; t < CT; t++)
-    for (int64_t s0 = tile_start[t]; s0 < tile_start[t] + hrel[t]; s0 += chunk) {
-      TileChunk ch{t, (int32_t)s0, (int32_t)std::min<int64_t>(s0 + chunk, tile_start[t] + hrel[t]),
-                   (int32_t)heavy_start[t]};
+  std::vector<TileChunk> queue[8];
+  H.need.assign((size_t)n_slabs * 2, 0);
+  // cut one run into chunks
+  auto cut_run = [&](int t, int64_t start, int64_t len, int32_t slab, std::vector<TileChunk> (&per_xcd)[8]) {
+    const bool heavy = slab < 0;
+    for (int64_t s0 = start; s0 < start + len; s0 += chunk) {
+      const int64_t e0 = std::min<int64_t>(s0 + chunk, start + len);
+      TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
+                   (int32_t)(heavy ? 0 : pdelta[(size_t)slab]), slab, 0, 0};
       per_xcd[xcd_order ? (t & 7) : 0].push_back(ch);
     }
-  size_t longest = 0;
-  for (auto &v : per_xcd) longest = std::max(longest, v.size());
-  if (!xcd_order)
-    H.chunks = per_xcd[0];
-  else
-    for (size_t i = 0; i < longest; i++)
-      for (int c = 0; c < 8; c++)
-        H.chunks.push_back(i < per_xcd[c].size() ? per_xcd[c][i] : TileChunk{0, 0, 0, 0});   // empty filler
+  };
+  // append per-XCD lists to H.chunks so that position p holds a chunk of XCD p % 8 (empty fillers where a list is short)
+  auto interleave = [&](std::vector<TileChunk> (&per_xcd)[8]) {
+    size_t longest = 0;
+    for (auto &v : per_xcd) longest = std::max(longest, v.size());
+    if (!xcd_order)
+      H.chunks.insert(H.chunks.end(), per_xcd[0].begin(), per_xcd[0].end());
+    else
+      for (size_t i = 0; i < longest; i++)
+        for (int c = 0; c < 8; c++)
+          H.chunks.push_back(i < per_xcd[c].size() ? per_xcd[c][i] : TileChunk{0, 0, 0, 0, 0, 0, 0, 0});   // empty filler
+  };
+  if (H.ring >= n_slabs) {
+    // No slot of P is reused: ONE phase-1 launch, tile by tile -- a tile's light chunks, then its heavy
+    // chunks -- so that memory-bound light chunks and the ALU-heavier heavy chunks are in flight together.
+    std::vector<TileChunk> per_xcd[8];
+    for (int t = 0; t < CT; t++) {
+      for (int64_t sl = 0; sl < n_slabs; sl++)
+        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, per_xcd);
+      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, per_xcd);
+    }
+    interleave(per_xcd);
+    H.slab_chunk0.assign((size_t)n_slabs, 0);
+    H.slab_chunk0.push_back((int32_t)H.chunks.size());   // [0, all) = everything ...
+    H.slab_chunk0.push_back((int32_t)H.chunks.size());   // ... and no separate heavy range
+  } else {
+    // P slots are reused: one phase-1 launch per slab (slab-major lists), the heavy chunks in a list of their own
+    for (int64_t sl = 0; sl < n_slabs; sl++) {
+      std::vector<TileChunk> per_xcd[8];
+      H.slab_chunk0.push_back((int32_t)H.chunks.size());
+      for (int t = 0; t < CT; t++)
+        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, per_xcd);
+      interleave(per_xcd);
+    }
+    std::vector<TileChunk> per_xcd[8];
+    H.slab_chunk0.push_back((int32_t)H.chunks.size());
+    for (int t = 0; t < CT; t++)
+      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, per_xcd);
+    interleave(per_xcd);
+    H.slab_chunk0.push_back((int32_t)H.chunks.size());
+  }
+  // the fused launch's queues: light chunks slab-major per XCD (no fillers), heavy chunks, per-slab counts
+  {
+    std::vector<TileChunk> tmp[8];
+    for (int64_t sl = 0; sl < n_slabs; sl++) {
+      for (auto &v : tmp) v.clear();
+      for (int t = 0; t < CT; t++)
+        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, tmp);
+      for (int q = 0; q < 8; q++) {
+        queue[q].insert(queue[q].end(), tmp[q].begin(), tmp[q].end());
+        H.need[(size_t)sl * 2] += (int32_t)tmp[q].size();
+      }
+    }
+    for (auto &v : tmp) v.clear();
+    for (int t = 0; t < CT; t++)
+      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, tmp);
+    for (int q = 0; q < 8; q++) H.hchunks.insert(H.hchunks.end(), tmp[q].begin(), tmp[q].end());
+  }
+  for (int q = 0; q < 8; q++) {
+    H.lq0[q] = (int32_t)H.qchunks.size();
+    H.qchunks.insert(H.qchunks.end(), queue[q].begin(), queue[q].end());
+  }
+  H.lq0[8] = (int32_t)H.qchunks.size();
+  for (int64_t sl = 0; sl < n_slabs; sl++)
+    H.need[(size_t)sl * 2 + 1] = H.slab_bin0[(size_t)sl + 1] - H.slab_bin0[(size_t)sl];
   return true;
 }
 
@@ -652,7 +781,8 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
   if (m->plan == PLAN_STREAM) {   // the tiled layout is of no further use
     for (void **p : {(void **)&m->d_bins, (void **)&m->d_chunks, (void **)&m->d_tval, (void **)&m->d_tcol, (void **)&m->d_gdest,
                      (void **)&m->d_pslot, (void **)&m->d_gsrc, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
-                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict}) {
+                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_qchunks, (void **)&m->d_hchunks,
+                     (void **)&m->d_lq0, (void **)&m->d_need, (void **)&m->d_ctl}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -743,6 +873,12 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     m->light_len = th.light_len;
     m->stream_len = th.stream_len;
     m->p_len = th.p_len;
+    m->slab_bin0 = th.slab_bin0;
+    m->slab_chunk0 = th.slab_chunk0;
+    m->slab_cap = th.slab_cap;
+    m->ring = th.ring;
+    const int64_t n_slabs = (int64_t)th.slab_bin0.size() - 1;
+    m->p_alloc = (th.ring >= n_slabs) ? th.light_len : (int64_t)th.ring * th.slab_cap;
     HIP_TRY_M(hipMalloc((void **)&m->d_bins, th.bins.size() * sizeof(RowBin)));
     HIP_TRY_M(hipMemcpyAsync(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_chunks, th.chunks.size() * sizeof(TileChunk)));
@@ -767,9 +903,40 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     HIP_TRY_M(hipMemcpyAsync(m->d_gsrc, th.gsrc.data(), th.gsrc.size() * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max(th.p_len, th.stream_len) * 4 + 16));
+    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max<int64_t>(m->p_alloc, 4) * 4 + 16));
     HIP_TRY_M(hipMalloc((void **)&m->d_lrp, th.lrp.size() * 4));
     HIP_TRY_M(hipMemcpyAsync(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, hipMemcpyHostToDevice, e->stream));
+    {
+      // the fused launch needs every workgroup resident at once: one per CU (LDS), grid = CU count
+      // Opt-in (SH_FUSED=1): measured slower than two launches on MI355X -- both roles are bound by what one CU
+      // keeps in flight, not by HBM, so running them side by side on half the CUs each gains nothing
+      // ("slab-pipelined fused launch"; profiles/r02_fused_*).
+      const char *fz = getenv("SH_FUSED");
+      m->fused = fz && fz[0] == '1' && e->n_cus >= 16;
+      m->n2 = 16;
+      if (const char *v = getenv("SH_N2")) m->n2 = atoi(v);
+      m->n2 = std::max(1, std::min(m->n2, e->n_cus / 8 - 1));
+      // A phase-2 worker waits for its NEXT bin's slab while its current bin is unfinished.  That is only
+      // free of cycles if the next bin (8 * n2 bins further) is at most one slab ahead and the slab after
+      // the current one does not need the current one's ring slot: every slab but the last must hold
+      // >= 8 * n2 bins, and the ring >= 2 slots (kernels.hip.h, tiled_phase2_run).
+      int32_t min_bins = INT32_MAX;
+      for (int64_t sl = 0; sl + 1 < n_slabs; sl++)
+        min_bins = std::min(min_bins, th.slab_bin0[(size_t)sl + 1] - th.slab_bin0[(size_t)sl]);
+      m->n2 = std::min(m->n2, min_bins / 8);
+      if (m->n2 < 1 || (n_slabs > 1 && th.ring < 2)) m->fused = false;
+      m->n_hchunks = (int32_t)th.hchunks.size();
+      m->ctl_words = CTL_GATES + GATE_WORDS * (1 + 2 * (int32_t)n_slabs);
+      HIP_TRY_M(hipMalloc((void **)&m->d_qchunks, (th.qchunks.size() + 1) * sizeof(TileChunk)));
+      HIP_TRY_M(hipMemcpyAsync(m->d_qchunks, th.qchunks.data(), th.qchunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_hchunks, (th.hchunks.size() + 1) * sizeof(TileChunk)));
+      HIP_TRY_M(hipMemcpyAsync(m->d_hchunks, th.hchunks.data(), th.hchunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_lq0, sizeof th.lq0));
+      HIP_TRY_M(hipMemcpyAsync(m->d_lq0, th.lq0, sizeof th.lq0, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_need, (th.need.size() + 2) * 4));
+      HIP_TRY_M(hipMemcpyAsync(m->d_need, th.need.data(), th.need.size() * 4, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMalloc((void **)&m->d_ctl, (size_t)m->ctl_words * 4));
+    }
     if (m->n_tlong) {
       HIP_TRY_M(hipMalloc((void **)&m->d_tlong, th.heavy.size() * sizeof(LongRow)));
       HIP_TRY_M(hipMemcpyAsync(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
@@ -807,7 +974,8 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
                   (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
-                  (void *)m->d_tcode, (void *)m->d_vdict})
+                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_qchunks, (void *)m->d_hchunks, (void *)m->d_lq0,
+                  (void *)m->d_need, (void *)m->d_ctl})
     if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
@@ -852,9 +1020,13 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     char vals[32];
     if (m->n_vdict) snprintf(vals, sizeof vals, "dict%d(%d)", m->code_bits, m->n_vdict_used);
     else snprintf(vals, sizeof vals, "raw");
-    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM", vals,
+    char slabs[64];
+    const int n_slabs = (int)m->slab_bin0.size() - 1;
+    if (m->ring >= n_slabs) snprintf(slabs, sizeof slabs, "slabs=%d", n_slabs);
+    else snprintf(slabs, sizeof slabs, "slabs=%d ring=%dx%.2fMB", n_slabs, m->ring, m->slab_cap * 4 / 1048576.0);
+    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM %s%s", vals,
              (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
-             m->light_len / 1e6);
+             m->light_len / 1e6, slabs, m->fused ? " fused" : "");
   } else {
     snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);
   }
@@ -929,7 +1101,7 @@ int sh_vec_download(sh_engine *e, const sh_vec *v, void *host, int64_t n) {
     return fail(e, SH_ESHAPE, "sh_vec_download: %lld elements from a vector of %lld", (long long)n, (long long)v->n);
   HIP_TRY(e, hipMemcpyAsync(host, v->d, n * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return SH_OK;
+  return check_gave_up(e);
 }
 
 int sh_vec_fill(sh_engine *e, sh_vec *v, uint32_t pattern32) {
@@ -970,51 +1142,101 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
   if (A->plan == PLAN_TILED) {
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
-    if (A->n_vdict && A->code_bits == 4)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
-                         A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
-    else if (A->n_vdict)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
-                         A->d_chunks, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), dim3(A->n_chunks), dim3(TBS), 0, e->stream,
-                         A->d_chunks, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
-                         (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial);
-    HIP_TRY(e, hipGetLastError());
-    const char *p2 = getenv("SH_P2");
-    const bool classic_p2 = p2 && !strcmp(p2, "classic");
-    if (!classic_p2 && A->n_bins > 0) {
-      // wave-specialised phase 2; its reducer waves also add up the heavy rows' partials while
-      // the loaders fill the first image, so one SpMV is two launches
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
-                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
-                         A->d_gsrc, A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
-                         (uint32_t *)out->d, st);
+    auto phase1 = [&](int32_t c0, int32_t c1) {
+      if (c1 <= c0) return;
+      const TileChunk *ch = A->d_chunks + c0;
+      if (A->n_vdict && A->code_bits == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
+                           ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+      else if (A->n_vdict)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
+                           ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
+                           ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+    };
+    const int n_slabs = (int)A->slab_bin0.size() - 1;
+    if (A->fused) {
+      // one persistent launch: phase-1 and phase-2 workers side by side, slab hand-offs through counters
+      FusedDev D{};
+      D.qchunks = A->d_qchunks; D.lq0 = A->d_lq0; D.hchunks = A->d_hchunks; D.n_hchunks = A->n_hchunks;
+      D.cols = (int32_t)A->cols;
+      D.tval = A->n_vdict ? (const void *)A->d_tcode : (const void *)A->d_tval;
+      D.vdict = A->d_vdict; D.tcol = A->d_tcol; D.gdest = A->d_gdest; D.x = (const uint32_t *)x->d;
+      D.P = A->d_P; D.p_bytes = (uint32_t)(A->p_alloc * 4); D.last_group = (int32_t)(A->p_alloc / 4 - 1);
+      D.partial = A->d_tpartial; D.bins = A->d_bins; D.lrp = A->d_lrp; D.pslot = A->d_pslot; D.gsrc = A->d_gsrc;
+      D.heavy_rows = A->d_tlong; D.need = A->d_need; D.ctl = A->d_ctl; D.err = (uint32_t *)(e->h_flag + 8);
+#ifdef SH_STATS
+      static uint64_t *g_stats = nullptr;
+      if (!g_stats) (void)hipMalloc((void **)&g_stats, 8192 * 8);
+      D.stats = g_stats;
+      D.dbg = getenv("SH_DBG") ? atoi(getenv("SH_DBG")) : 0;
+#endif
+      D.n_bins = A->n_bins; D.n_heavy = A->n_tlong; D.n_slabs = n_slabs; D.ring = A->ring; D.n2 = A->n2;
+      HIP_TRY(e, hipMemsetAsync(A->d_ctl, 0, (size_t)A->ctl_words * 4, e->stream));
+      const dim3 grid((unsigned)(e->n_cus & ~7));
+      if (A->n_vdict && A->code_bits == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 2>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
+                           use_y ? 1 : 0, (uint32_t *)out->d, st);
+      else if (A->n_vdict)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 1>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
+                           use_y ? 1 : 0, (uint32_t *)out->d, st);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 0>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
+                           use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
+#ifdef SH_STATS
+      if (getenv("SH_STATS_DUMP")) {   // development builds only: per-role timeline of this launch (100 MHz ticks -> us)
+        std::vector<uint64_t> hs((size_t)grid.x * 8), sl((size_t)n_slabs * 2);
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipMemcpy(hs.data(), g_stats, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sl.data(), g_stats + 4096, sl.size() * 8, hipMemcpyDeviceToHost);
+        uint64_t t0 = ~0ull;
+        for (unsigned w = 0; w < grid.x; w++) t0 = std::min(t0, hs[w * 8 + 2]);
+        fprintf(stderr, "[stats] slab produced / consumed at (us):");
+        for (int i = 0; i < n_slabs; i++) fprintf(stderr, " %d: %.0f/%.0f", i, (sl[2 * i] - t0) / 100.0, (sl[2 * i + 1] - t0) / 100.0);
+        fprintf(stderr, "\n");
+        for (int role = 0; role < 2; role++) {
+          double n = 0, items = 0, main_end = 0, heavy_end = 0, end = 0, wait = 0, heavy = 0, start = 0, max_end = 0, max_main = 0;
+          for (unsigned w = 0; w < grid.x; w++) {
+            const uint64_t *S = &hs[w * 8];
+            if ((int)S[0] != role) continue;
+            n++; items += S[1]; start += (S[2] - t0) / 100.0; main_end += (S[3] - t0) / 100.0; heavy_end += (S[4] - t0) / 100.0;
+            end += (S[7] - t0) / 100.0; wait += S[5] / 100.0; heavy += S[6];
+            max_end = std::max(max_end, (S[7] - t0) / 100.0); max_main = std::max(max_main, (S[3] - t0) / 100.0);
+          }
+          if (n > 0)
+            fprintf(stderr, "[stats] role %s: %3.0f WGs, items/WG %.1f, start %.1f us, main loop ends avg %.1f max %.1f, heavy queue ends %.1f (%.1f chunks/WG), "
+                    "kernel end avg %.1f max %.1f, waiting %.1f us/WG\n", role ? "phase2" : "phase1", n, items / n, start / n, main_end / n, max_main,
+                    heavy_end / n, heavy / n, end / n, max_end, wait / n);
+        }
+      }
+#endif
       return SH_OK;
     }
-    // classic phase 2 (SH_P2=classic, or no light bins at all).  Heavy rows only need phase 1's
-    // partials and write rows phase 2 never touches: fork them onto the side stream.
-    const bool fork = A->n_tlong > 0 && A->n_bins > 0;
-    if (fork) {
-      HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-      HIP_TRY(e, hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->aux, A->d_tlong,
-                         A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+    // separate launches (SH_FUSED=0).  The heavy rows' (row, tile) sums first: they only feed the partials
+    phase1(A->slab_chunk0[(size_t)n_slabs], A->slab_chunk0[(size_t)n_slabs + 1]);
+    HIP_TRY(e, hipGetLastError());
+    // With a ring, slab by slab: phase 2 of a slab has to finish before a later slab may overwrite its
+    // slot.  Without slot reuse (ring >= slabs) one phase-1 and one phase-2 launch cover everything.  The
+    // last phase-2 launch's reducer waves also add up the heavy rows' partials.
+    const int step = A->ring >= n_slabs ? std::max(n_slabs, 1) : 1;
+    for (int sl = 0; sl < n_slabs; sl += step) {
+      const int sl1 = std::min(n_slabs, sl + step);
+      phase1(A->slab_chunk0[(size_t)sl], A->slab_chunk0[(size_t)sl1]);
       HIP_TRY(e, hipGetLastError());
-      HIP_TRY(e, hipEventRecord(e->ev_join, e->aux));
-    }
-    if (A->n_bins > 0) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2<SR>), dim3(std::min(A->n_bins, e->n_cus * (32768 / TBIN))), dim3(T2BS), 0,
-                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(A->stream_len / 4 - 1), A->d_pslot,
-                         A->d_gsrc, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
+      const int32_t b0 = A->slab_bin0[(size_t)sl], nb = A->slab_bin0[(size_t)sl1] - b0;
+      const bool last = sl1 == n_slabs;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(nb, e->n_cus)), dim3(P2S_BS), 0,
+                         e->stream, A->d_bins + b0, nb, A->d_lrp, A->d_P, (int32_t)(A->p_alloc / 4 - 1), A->d_pslot,
+                         A->d_gsrc, A->d_tlong, last ? A->n_tlong : 0, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
+                         (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
-    if (fork) {
-      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
-    } else if (A->n_tlong > 0) {
+    if (A->n_bins == 0 && A->n_tlong > 0) {   // every row is heavy: no phase 2 to host the sums
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,
                          A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
@@ -1086,6 +1308,7 @@ int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, cons
     float ms = 0.f;
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
     *kernel_ns = (uint64_t)((double)ms * 1e6);
+    return check_gave_up(e);
   }
   return SH_OK;
 }
@@ -1135,6 +1358,7 @@ int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const s
     HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->h_flag, e->d_flags, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (int gu = check_gave_up(e)) return gu;
     float ms = 0.f;
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
     const uint64_t ns = (uint64_t)((double)ms * 1e6);

@@ -55,6 +55,21 @@ struct StepDev {
 struct LongSeg { int32_t row, s, e, slot; };
 struct LongRow { int32_t row, slot0, nslots, pad; };
 
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+
+// Hand-off discipline of the fused launch (spmv_tiled_fused below; MI355X_MICROARCH.md "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility"): bytes one workgroup produces for another
+// inside a launch (P, heavy partials) are stored write-through (sc1), every storing wave drains
+// vmcnt, the workgroup meets at a barrier, ONE lane bumps an agent-scope counter; the consumer polls
+// that counter with relaxed agent-scope loads and reads the bytes with sc1 loads only.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
 // outstanding global load (s_waitcnt vmcnt(0)), which would serialise the register prefetch
 // of the next bin behind the current bin's LDS work; the kernels below exchange data between
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
 // The same sum by ONE wave (bit-identical: lane l plays threads l, l+64, l+128, l+192 of the block
 // above).  Used by the wave-specialised phase 2, whose reducer waves are idle while the loaders
 // fill the first bin.
-template <class SR>
+template <class SR, bool SC1>
 __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__restrict__ partial, int lane,
                                          const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
                                          bool use_y, uint32_t *__restrict__ out, const StepDev &st) {
@@ -357,7 +372,6 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
   for (int w = 0; w < HFIX_BS / 64; w++)
     acc[w] = SR::identity();
   constexpr int HU = 4;   // chunks of HFIX_BS partials in flight per lane (a row can have thousands)
-  const uint32_t ident = to_bits<T>(SR::identity());
   for (int k0 = 0; k0 < lr.nslots; k0 += HFIX_BS * HU) {
     uint32_t v[HU][HFIX_BS / 64];
 #pragma unroll
@@ -365,7 +379,8 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 #pragma unroll
       for (int w = 0; w < HFIX_BS / 64; w++) {
         const int k = k0 + u * HFIX_BS + w * 64 + lane;
-        v[u][w] = partial[lr.slot0 + min(k, lr.nslots - 1)];   // clamped: branch-free, all loads fly together
+        // clamped: branch-free, all loads fly together (SC1: partials written by other workgroups of this launch)
+        v[u][w] = SC1 ? ld_agent(partial + lr.slot0 + min(k, lr.nslots - 1)) : partial[lr.slot0 + min(k, lr.nslots - 1)];
       }
 #pragma unroll
     for (int u = 0; u < HU; u++)
@@ -376,7 +391,6 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
           acc[w] = SR::add(acc[w], from_bits<T>(v[u][w]));
       }
   }
-  (void)ident;
 #pragma unroll
   for (int w = 0; w < HFIX_BS / 64; w++) {
 #pragma unroll
@@ -430,7 +444,6 @@ constexpr int TBS = 1024;               // threads per phase-1 workgroup
 #define SH_TBIN 16384   // 32768: one 1024-thread WG per CU; 16384: two 512-thread WGs (measured 5 % faster)
 #endif
 constexpr int TBIN = SH_TBIN;           // products per row bin (LDS image: 4 B each)
-constexpr int T2BS = TBIN / 32;         // threads per phase-2 workgroup (P2U = 8 groups of 4 each)
 constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #ifndef SH_TCHUNK
 #define SH_TCHUNK 32768
@@ -443,15 +456,19 @@ constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread i
 constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
 static_assert(TCOLS % 4 == 0 && TCOLS < 65536 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
-constexpr uint32_t THEAVY = 0x80000000u;   // gdest flag: group belongs to a heavy row, low bits = partial slot
+// gdest word of a heavy group: partial slot | (groups of the same partial to its left in the wave) << 25
+// | (last group of its partial) << 31
+constexpr int GD_DIST_SHIFT = 25;
+constexpr uint32_t GD_SLOT_MASK = (1u << GD_DIST_SHIFT) - 1, GD_LAST = 0x80000000u;
 
-// entries [s,e) of the tile-major stream; positions >= hs belong to heavy rows (each tile's stream
-// is [light pieces][heavy pieces])
-struct TileChunk { int32_t tile, s, e, hs; };
+// entries [s,e) of the stream (slab-major light runs, then the tiles' heavy runs); positions >= hs
+// belong to heavy rows.  A light product at stream position q goes to P[q + pdelta] (the slab's slot
+// of the P ring); slab = -1 for heavy chunks.
+struct TileChunk { int32_t tile, s, e, hs, pdelta, slab, pad0, pad1; };
 // r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
-// n: products incl. padding at P[pstart .. pstart+n); pslot >= 0: the bin is one piece of a
-// long row and its result goes to partial[pslot].
-struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, pslot, pad; };
+// n: products incl. padding; pstart: where the bin's slots / P sources start in pslot[] / gsrc[]
+// (bin-major); slab: the slab (slot of the P ring) its products travel in.
+struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, slab, pad; };
 
 // Value coding (VC): when the matrix holds at most 256 distinct 4-byte values (always true for
 // pattern files, and for every file once the reference's int narrowing -- quirk A-3 -- has been
@@ -464,53 +481,89 @@ struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, pslot, pad; };
 constexpr int P1U_VC = SH_P1_UNROLL_VC;
 constexpr int VDICT = 256;
 
+// Segmented inclusive scan over a wave: lane i ends up with (+) of t over lanes [i - dist, i]
+// (dist = lanes of the same segment to the left).  Hillis-Steele inside each row of 16 lanes
+// (row_shr DPP), then the row tails travel down by row_bcast:15 (rows 1, 3) and row_bcast:31
+// (rows 2, 3).  The order of the additions is fixed by the lane position alone.
+template <class SR>
+__device__ __forceinline__ typename SR::T seg_scan_wave(typename SR::T t, const int dist, const int lane) {
+  using T = typename SR::T;
+  const int idb = (int)to_bits<T>(SR::identity());
+  const int lr = lane & 15, dr = min(dist, lr);
+#define SH_SEG_STEP(O)                                                                                              \
+  {                                                                                                                 \
+    const T up = from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(idb, (int)to_bits<T>(t), 0x110 + O, 0xF, 0xF, false)); \
+    if (dr >= O) t = SR::add(t, up);                                                                                \
+  }
+  SH_SEG_STEP(1) SH_SEG_STEP(2) SH_SEG_STEP(4) SH_SEG_STEP(8)
+#undef SH_SEG_STEP
+  {
+    const T up = from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(idb, (int)to_bits<T>(t), 0x142, 0xA, 0xF, false));   // row_bcast:15
+    if ((lane & 16) && dist > lr) t = SR::add(t, up);
+  }
+  {
+    const T up = from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(idb, (int)to_bits<T>(t), 0x143, 0xC, 0xF, false));   // row_bcast:31
+    if (lane >= 32 && dist > (lane & 31)) t = SR::add(t, up);
+  }
+  return t;
+}
+
 // VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
-template <class SR, int VC>
-__global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
-    const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
+// WT: products / partials are handed to other workgroups of the SAME launch: write-through stores
+//     (the caller drains and signals).  xs: [TCOLS + 4] words of LDS, ds: [VDICT].
+struct NoHook { __device__ void operator()() const {} };
+// staged(): called by every thread right after the barrier that publishes the x tile.  WT callers
+// signal the PREVIOUS chunk there: every wave has waited for its staging loads by then, and with
+// them (vmcnt counts in issue order) for the stores of the chunk before.
+template <class SR, int VC, bool WT, class Hook = NoHook>
+__device__ __forceinline__ void tiled_phase1_chunk(
+    const TileChunk ch, uint32_t *xs, uint32_t *ds, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t *__restrict__ partial) {
+    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial, Hook staged = NoHook()) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
   // the value words of one group of 4 entries: 4 values, 4 one-byte codes, or 4 nibbles
   using VWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint32_t, uint16_t>::type>::type;
   // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
-#ifndef SH_XS_EXTRA
-#define SH_XS_EXTRA 0
-#endif
-  __shared__ uint32_t xs[TCOLS + 4 + SH_XS_EXTRA];
-  __shared__ uint32_t ds[VC ? VDICT : 1];
   const VWord *__restrict__ tval = reinterpret_cast<const VWord *>(tval_or_code);
   const uint2 *__restrict__ tcol2 = reinterpret_cast<const uint2 *>(tcol);
-  const TileChunk ch = chunks[blockIdx.x];
-  if (ch.s >= ch.e)
-    return;   // filler that keeps the XCD-aligned chunk order
   const int tid = threadIdx.x;
+  __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(P, 0, (int)p_bytes, 0x00020000);
   const int c0 = ch.tile * TCOLS;
   const uint32_t ident = to_bits<T>(SR::identity());
   if (VC && tid < VDICT)
     ds[tid] = vdict[tid];
   if (tid == 0)
     xs[TCOLS] = ident;
-  // stage the x tile: cols is arbitrary, x is only guaranteed 4-byte aligned
-  if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    // full tile, 16-byte aligned: 1 KiB per wave-instruction; every load is issued before the first
-    // LDS write (a rolled loop would pay one memory latency per iteration)
-    constexpr int NI = (TCOLS / 4 + TBS - 1) / TBS;
-    uint4 t[NI];
+  // Stage the x tile (cols is arbitrary, x is only guaranteed 4-byte aligned), then request the chunk's
+  // first stream batch.  (Requesting it right behind the staging loads, so that its HBM latency runs
+  // under the LDS writes, was measured SLOWER on the same box: 533 vs 508 us per SpMV.)
+  // Every wave waits for staging loads here, and with them -- vmcnt counts in issue order -- for the
+  // stores of the chunk it processed before: that is what lets a WT caller signal that chunk in staged().
+  auto stage = [&](auto request_first) {
+    if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      // full tile, 16-byte aligned: 1 KiB per wave-instruction; every load is issued before the first
+      // LDS write (a rolled loop would pay one memory latency per iteration)
+      constexpr int NI = (TCOLS / 4 + TBS - 1) / TBS;
+      uint4 t[NI];
 #pragma unroll
-    for (int k = 0; k < NI; k++)
-      t[k] = reinterpret_cast<const uint4 *>(x + c0)[min(tid + k * TBS, TCOLS / 4 - 1)];
+      for (int k = 0; k < NI; k++)
+        t[k] = reinterpret_cast<const uint4 *>(x + c0)[min(tid + k * TBS, TCOLS / 4 - 1)];
 #pragma unroll
-    for (int k = 0; k < NI; k++)
-      if (tid + k * TBS < TCOLS / 4)
-        reinterpret_cast<uint4 *>(xs)[tid + k * TBS] = t[k];
-  } else {
-    for (int i = tid; i < TCOLS; i += TBS)
-      xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
-  }
-  __syncthreads();
+      for (int k = 0; k < NI; k++)
+        if (tid + k * TBS < TCOLS / 4)
+          reinterpret_cast<uint4 *>(xs)[tid + k * TBS] = t[k];
+    } else {
+      for (int i = tid; i < TCOLS; i += TBS)
+        xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
+      if constexpr (WT)   // (a wave past the end of a partial tile has loaded nothing: drain the older stores explicitly)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    staged();
+    request_first();
+  };
   // the four products of one 16-byte group: x gathered from LDS, values decoded when coded
   auto products = [&](const VWord &w, const uint2 &c, T (&pr)[4]) {
     uint4 v;
@@ -532,8 +585,9 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   // ---- light entries: products go to P at the entry's own stream position (16-byte stores)
   // (ping-pong register sets A/B instead of a copy at the loop end: a copy would wait for the
   // loads it copies)
+  // A chunk is either all light (hs == e) or all heavy (hs <= s): the plan builder cuts them apart.
   const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
-  {
+  if (ch.hs > ch.s) {
     constexpr int S = TBS * U;
     auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U]) {
 #pragma unroll
@@ -550,15 +604,20 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
         if (g < le) {
           T pr[4];
           products(vw[k], c[k], pr);
-          reinterpret_cast<uint4 *>(P)[g] = make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+          if constexpr (WT) {
+            const v4u32 pv = {to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, (g * 4 + ch.pdelta) * 4, 0, 16);   // aux 16 = sc1
+          } else {
+            reinterpret_cast<uint4 *>(P + ch.pdelta)[g] = make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+          }
         }
       }
     };
     VWord va[U], vb[U];
     uint2 ca[U], cb[U];
     int g0 = ch.s / 4 + tid;
+    stage([&]() { load(g0, va, ca); });
     if (g0 < le) {
-      load(g0, va, ca);
       for (;;) {
         load(g0 + S, vb, cb);
         consume(g0, va, ca);
@@ -572,13 +631,14 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     }
   }
   // ---- heavy entries (rows averaging >= 8 entries per tile): their products never travel
-  // through P.  gdest holds the partial slot of each group; consecutive lanes with the same slot
-  // are one (row, tile, wave-part) piece: segmented inclusive scan over the wave, the last lane
-  // of the piece stores the sum.  Wave boundaries are fixed by the stream position, so the plan
-  // builder knows every piece's split in advance (deterministic, no atomics).
+  // through P.  Consecutive lanes whose groups share a partial slot are one (row, tile, wave-part)
+  // piece: segmented inclusive scan over the wave, the last lane of the piece stores the sum.  Wave
+  // boundaries are fixed by the stream position, so the plan builder knows every piece's split in
+  // advance and stores, per group, the slot, how far the piece reaches to the left and whether the
+  // group ends it (gdest): no key travels between lanes (deterministic, no atomics).
   const int hb = max(ch.s, min(ch.e, ch.hs)) / 4, he = ch.e / 4;
   const int lane = tid & 63;
-  {
+  if (ch.hs <= ch.s) {
     constexpr int S = TBS * U;
     auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U], uint32_t (&d)[U]) {
 #pragma unroll
@@ -601,17 +661,12 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
             products(vw[k], c[k], pr);
             t = SR::add(SR::add(SR::add(pr[0], pr[1]), pr[2]), pr[3]);
           }
-          const uint32_t key = valid ? d[k] : (0x80000000u | (uint32_t)lane);   // invalid lanes never merge
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const T up = from_bits<T>(__shfl_up(to_bits<T>(t), o, 64));
-            const uint32_t kk = __shfl_up(key, o, 64);
-            if (lane >= o && kk == key)
-              t = SR::add(t, up);
+          // segmented inclusive scan, all in DPP (no LDS traffic: phase 1's LDS is busy gathering x)
+          t = seg_scan_wave<SR>(t, valid ? (int)((d[k] >> GD_DIST_SHIFT) & 63u) : 0, lane);
+          if (valid && (d[k] & GD_LAST)) {
+            if constexpr (WT) st_agent(partial + (d[k] & GD_SLOT_MASK), to_bits<T>(t));
+            else partial[d[k] & GD_SLOT_MASK] = to_bits<T>(t);
           }
-          const uint32_t knext = __shfl_down(key, 1, 64);
-          if (valid && (lane == 63 || knext != key))
-            partial[d[k]] = to_bits<T>(t);
         }
       }
     };
@@ -620,8 +675,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     uint32_t da[U], db[U];
     // start on the 64-group boundary (relative to the chunk start) the builder assumed
     int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid;
+    stage([&]() { load(g0, va, ca, da); });
     if (g0 < he) {
-      load(g0, va, ca, da);
       for (;;) {
         load(g0 + S, vb, cb, db);
         consume(g0, va, ca, da);
@@ -636,12 +691,24 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   }
 }
 
-// Phase 2 is persistent: each workgroup walks bins b = blockIdx.x, += gridDim.x and keeps the
-// NEXT bin's products (and their slots) in registers while it reduces the current one out of
-// LDS, so the HBM stream of bin b+1 overlaps the LDS work of bin b.  With 16384-product bins two
-// such workgroups share a CU (2 x 64 KiB images), which also keeps HBM requests in flight while
-// one of them sits between its barriers.
-constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers T2BS*P2U*4 = 32768 products)
+
+template <class SR, int VC>
+__global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
+    const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
+    const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
+    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
+    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial) {
+  __shared__ uint32_t xs[TCOLS + 4];
+  __shared__ uint32_t ds[VC ? VDICT : 1];
+  const TileChunk ch = chunks[blockIdx.x];
+  if (ch.s >= ch.e)
+    return;   // filler that keeps the XCD-aligned chunk order
+#ifdef SH_FORCE_WT   // tuning builds: write-through stores in the separate launches too
+  tiled_phase1_chunk<SR, VC, true>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
+#else
+  tiled_phase1_chunk<SR, VC, false>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
+#endif
+}
 
 // The prefetch of phase 2 goes through inline-asm loads.  hipcc tracks vmcnt only for loads it
 // emitted itself and is conservative across the loop back-edge: with compiler-visible loads it
@@ -650,8 +717,6 @@ constexpr int P2U = 8;   // groups of 4 products a thread prefetches (covers T2B
 // with nothing else in flight).  With asm loads the compiler inserts no waits for them at all;
 // the single hand-placed wait is phase2_wait_all() at the top of the loop, whose operand list
 // ties every prefetch register to it so that no use can be scheduled above it.
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
-typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void async_load(v4u32 &dst, const void *addr) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
 }
@@ -660,132 +725,6 @@ __device__ __forceinline__ void async_load(v2u32 &dst, const void *addr) {
 }
 __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
-}
-
-template <class SR>
-__global__ __launch_bounds__(T2BS) void spmv_tiled_phase2(
-    const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
-    const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
-    const uint32_t *__restrict__ gsrc, const uint32_t *__restrict__ y, typename SR::T alpha,
-    typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
-
-  __shared__ uint32_t prod[TBIN];
-  __shared__ int32_t rp[TBIN_ROWS + 1];
-  __shared__ ReduceScratch<T2BS, TBIN> sc;
-  const int tid = threadIdx.x;
-  const bool use_y = use_y_i != 0;
-  const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
-  static_assert(P2U == 8, "phase2_wait_all lists the prefetch registers explicitly");
-  constexpr int RPU = TBIN_ROWS / T2BS + 1;   // row_ptr entries a thread prefetches
-  static_assert(RPU == 5, "phase2_wait_all lists the prefetch registers explicitly");
-
-  v4u32 p[P2U];        // products of the bin about to be scattered ...
-  v2u32 s[P2U];        // ... and their slots
-  uint32_t gs[P2U];    // gsrc of the bin after it (the P addresses of the next prefetch)
-  uint32_t rpr[RPU];   // raw light row offsets of the bin about to be scattered
-  // All prefetch loads are unconditional on clamped indices; the predicate is applied when the
-  // registers are consumed.
-  auto load_rp = [&](const RowBin &bn) {
-#pragma unroll
-    for (int k = 0; k < RPU; k++)
-      async_load(rpr[k], row_ptr + bn.r0 + min(tid + k * T2BS, bn.nr));
-  };
-  auto load_gs = [&](const RowBin &bn) {
-    const int n4 = max(bn.n / 4, 1);
-    const uint32_t *G4 = gsrc + bn.pstart / 4;
-#pragma unroll
-    for (int k = 0; k < P2U; k++)
-      async_load(gs[k], G4 + min(tid + k * T2BS, n4 - 1));
-  };
-  auto wait_all = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
-                   "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])
-                 :
-                 : "memory");
-    asm volatile(""
-                 : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]), "+v"(gs[7]),
-                   "+v"(rpr[0]), "+v"(rpr[1]), "+v"(rpr[2]), "+v"(rpr[3]), "+v"(rpr[4])
-                 :
-                 : "memory");
-  };
-  auto put = [&](v2u32 sl, v4u32 pr) {
-    const uint32_t sa = sl.x & 0xFFFFu, sb = sl.x >> 16, sc_ = sl.y & 0xFFFFu, sd = sl.y >> 16;
-    if (sa != TSLOT_PAD) prod[sa] = pr.x;
-    if (sb != TSLOT_PAD) prod[sb] = pr.y;
-    if (sc_ != TSLOT_PAD) prod[sc_] = pr.z;
-    if (sd != TSLOT_PAD) prod[sd] = pr.w;
-  };
-
-  // Workgroups are dealt round-robin over the 8 XCDs (blocks w and w+8 share one).  Neighbouring
-  // bins own neighbouring pieces of every tile in P, so the 128-B lines at piece boundaries are
-  // wanted by both: give consecutive bins to workgroups of the SAME XCD so that the shared line
-  // is fetched into one L2 once instead of into two (speed only; any placement is correct).
-  const int G = gridDim.x;
-#ifdef SH_NO_XCD_BINS
-  int b = (int)blockIdx.x;
-#else
-  int b = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-#endif
-  if (b >= n_bins)
-    return;
-  // (descriptors of bins that do not exist are read from the last bin instead: clamped scalar
-  // loads; a select against a dummy made hipcc use FLAT vector loads, whose wait drained the prefetch)
-  RowBin cur = bins[b];
-  RowBin nxt = bins[min(b + G, n_bins - 1)];
-  // prologue: the first bin's stream (its gsrc is an ordinary dependent load), then gsrc of the second
-  {
-    const int n4 = max(cur.n / 4, 1);
-    const uint32_t *G4 = gsrc + cur.pstart / 4;
-    const v2u32 *S4 = reinterpret_cast<const v2u32 *>(pslot + cur.pstart);
-    uint32_t src[P2U];
-#pragma unroll
-    for (int k = 0; k < P2U; k++)
-      src[k] = G4[min(tid + k * T2BS, n4 - 1)];
-#pragma unroll
-    for (int k = 0; k < P2U; k++) {
-      async_load(s[k], S4 + min(tid + k * T2BS, n4 - 1));
-      async_load(p[k], P4 + min((int32_t)(src[k] >> 2), last_group));
-    }
-    load_rp(cur);
-    load_gs(nxt);
-  }
-  for (; b < n_bins; b += G) {
-    const int n4 = cur.n / 4;
-    const bool has_next = b + G < n_bins;
-    const RowBin nxt2 = bins[min(b + 2 * G, n_bins - 1)];
-    wait_all();   // p/s/rpr of `cur` and gs of `nxt` are in registers now
-    // (the previous iteration ended with a barrier: prod/rp/sc are free)
-    if (tid < 4)
-      sc.cnt[tid] = 0;
-#pragma unroll
-    for (int k = 0; k < RPU; k++)
-      if (tid + k * T2BS <= cur.nr) {   // light row offsets; bit 31 = heavy row (skipped by the reduction)
-        const uint32_t v = rpr[k];
-        rp[tid + k * T2BS] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)cur.csr0) | ((v >> 31) ? RP_SKIP : 0);
-      }
-    // Scatter the current bin out of the registers and refill each register pair with the NEXT
-    // bin's group as soon as it is free: the next bin's whole stream is in flight before this
-    // bin's reduction starts, and gsrc of the bin after that right behind it.
-    const int nn4 = max(nxt.n / 4, 1);   // (no next bin: harmless re-read of the last bin's stream)
-    const v2u32 *S4n = reinterpret_cast<const v2u32 *>(pslot + nxt.pstart);
-#pragma unroll
-    for (int k = 0; k < P2U; k++) {
-      if (tid + k * T2BS < n4)
-        put(s[k], p[k]);
-      async_load(s[k], S4n + min(tid + k * T2BS, nn4 - 1));
-      async_load(p[k], P4 + min((int32_t)(gs[k] >> 2), last_group));   // clamp: a stale register must not fault
-    }
-    load_rp(nxt);
-    load_gs(nxt2);
-    lds_barrier();
-    reduce_rows_from_lds<SR, T2BS, TBIN>(prod, rp, cur.nr, cur.r0, sc, sc.cnt, tid, y, alpha, beta, use_y, out, st);
-    lds_barrier();
-    cur = nxt;
-    nxt = nxt2;
-    (void)has_next;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch must land before the wave ends
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,35 +756,104 @@ constexpr int P2S_NS = TBIN / 4 / P2S_Q;       // steps per bin: 4
 constexpr int P2S_RPU = (TBIN_ROWS + P2S_RD) / P2S_RD;   // row_ptr entries per reducer thread: 3
 static_assert(P2S_NS * P2S_Q * 4 == TBIN && P2S_NS % 2 == 0 && TBIN_ROWS + 1 <= P2S_RPU * P2S_RD, "phase-2 geometry");
 
-template <class SR>
-__global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
-    const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
-    const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
-    const uint32_t *__restrict__ gsrc, const LongRow *__restrict__ heavy_rows, int32_t n_heavy,
+// LDS of the phase-2 role
+struct P2Lds {
+  uint32_t prod[2][TBIN];
+  int32_t rp[2][TBIN_ROWS + 1];
+  uint32_t dots[TBIN_ROWS];
+  ReduceScratch<P2S_RD, TBIN> sc;
+  int32_t ready_slab;   // fused launch: THIS slab is known to be written (published by a reducer; gates open in any order)
+};
+
+// Gates: the fused launch's hand-off points ("all chunks of slab s are written", "all bins of slab s
+// are read", "all heavy chunks are done").  A gate is 64 words of the control block: word 0 counts
+// arrivals (touched by atomics only), word 32 -- a 128-B line of its own -- is the flag the LAST
+// arriver sets and the waiters poll.  Waiters never poll the counter: a few hundred pollers on the
+// word the producers' atomics target delayed those atomics (and everything in-order behind them in
+// the producers' vmcnt) by tens of microseconds.  Polls back off to ~4 us.
+constexpr int GATE_WORDS = 64, GATE_FLAG = 32;
+// SH_STATS builds (tools/, never the product): per-workgroup timeline of the fused launch in D.stats
+#ifdef SH_STATS
+#define SH_STAT(...) __VA_ARGS__
+#else
+#define SH_STAT(...)
+#endif
+__device__ __forceinline__ uint32_t gate_arrive(uint32_t *gate) {   // returns the arrivals before this one
+  return __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gate_finish(uint32_t *gate, uint32_t before, uint32_t need) {
+  if (before + 1 == need) st_agent(gate + GATE_FLAG, 1u);
+}
+__device__ __forceinline__ bool gate_is_open(const uint32_t *gate) { return ld_agent(gate + GATE_FLAG) != 0; }
+// Bounded wait (wave-uniform); a give-up sets *err (host-visible) and lets the caller run on, so that
+// the grid always drains; after the first give-up nothing waits any more.
+constexpr uint32_t SPIN_LIMIT = 1u << 19;   // x ~2-4 us
+__device__ __forceinline__ void gate_wait(const uint32_t *gate, uint32_t *err, bool &gave_up, uint64_t *ticks = nullptr) {
+  uint32_t spins = 0;
+  SH_STAT(const uint64_t t0 = __builtin_amdgcn_s_memrealtime();)
+  while (!gave_up && !gate_is_open(gate)) {
+    if (spins < 4) __builtin_amdgcn_s_sleep(8);
+    else if (spins < 16) __builtin_amdgcn_s_sleep(32);
+    else __builtin_amdgcn_s_sleep(127);
+    if (++spins > SPIN_LIMIT) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gave_up = true;
+    }
+  }
+  SH_STAT(if (ticks) *ticks += __builtin_amdgcn_s_memrealtime() - t0;)
+}
+__device__ __forceinline__ void async_load_sc1(v4u32 &dst, const void *addr) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(addr) : "memory");
+}
+
+// One workgroup's share of phase 2: bins b0, b0 + stride, ... (nb of them) of bins[].
+// FUSED: the bins' products are written by phase-1 workgroups of the SAME launch: before a loader
+// wave issues the first P load of a bin in a new slab that slab's "written" gate must be open (a
+// reducer lane polls it two bins ahead and publishes the result in LDS, so that the loaders' vmcnt
+// window is normally not disturbed; otherwise the loader waits itself); P is read with sc1 loads;
+// after a bin's image is complete one lane arrives at the slab's "read" gate (the ring slot may be
+// overwritten once all of the slab's bins did).  gates: [written(s)], then [read(s)], s < n_slabs.
+template <class SR, bool FUSED>
+__device__ __forceinline__ void tiled_phase2_run(
+    P2Lds &L, const RowBin *__restrict__ bins, const int b0, const int nb, const int stride,
+    const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ P, int32_t last_group,
+    const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
+    const LongRow *__restrict__ heavy_rows, int32_t n_heavy, int32_t heavy_first, int32_t heavy_stride,
     const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
-    typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
-  __shared__ uint32_t prod[2][TBIN];
-  __shared__ int32_t rp[2][TBIN_ROWS + 1];
-  __shared__ uint32_t dots[TBIN_ROWS];
-  __shared__ ReduceScratch<P2S_RD, TBIN> sc;
+    typename SR::T beta, const bool use_y, uint32_t *__restrict__ out, const StepDev &st,
+    uint32_t *gates, int32_t n_slabs, const int32_t *__restrict__ need, uint32_t *err, uint64_t *wait_ticks = nullptr, uint64_t *slab_t = nullptr) {
+  auto &prod = L.prod;
+  auto &rp = L.rp;
+  auto &dots = L.dots;
+  auto &sc = L.sc;
   const int tid = threadIdx.x;
-  const bool use_y = use_y_i != 0;
   // epilogues that read y or the previous vector run as a coalesced pass after one more barrier (MID2)
   const bool staged = use_y || st.changed != nullptr;
-  const int G = gridDim.x;
-  // consecutive bins on one XCD (see spmv_tiled_phase2)
-  const int b0 = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  if (b0 >= n_bins)
-    return;
-  const int nb = (n_bins - b0 + G - 1) / G;    // bins of this workgroup: b0, b0+G, ...
-  auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * G]; };   // clamped: scalar loads
+  auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * stride]; };   // clamped: scalar loads
   if (tid < 8)
     sc.cnt[tid] = 0;
+  if (FUSED && tid == 8)
+    L.ready_slab = -1;
   lds_barrier();
 
   if (tid < P2S_LD) {
     // ------------------------------------------------------------------ loaders
     const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
+    int ready_slab = -1;   // this wave has seen the gates of its bins' slabs up to this one open (FUSED)
+    bool gave_up = false;
+    // (the wait for the NEXT bin's slab happens while the current bin is unfinished: the host makes sure
+    // that a worker's next bin is at most one slab ahead and that the ring has two slots or more, so the
+    // chunks waited for never depend on this bin's completion)
+    auto ensure = [&](const RowBin &bn) {
+      if constexpr (FUSED) {
+        if (bn.slab > ready_slab) {
+          const int pub = *(volatile int32_t *)&L.ready_slab;   // (exactly this slab: an open gate says nothing about earlier slabs)
+          if (pub != bn.slab && need[2 * bn.slab] > 0)
+            gate_wait(gates + bn.slab * GATE_WORDS, err, gave_up, wait_ticks);
+          ready_slab = bn.slab;
+        }
+      }
+    };
     // addresses of step q = 4*j + quarter
     auto issue_gs = [&](const RowBin &bn, int quarter, uint32_t (&g)[P2S_K]) {
       const int n4 = max(bn.n / 4, 1);
@@ -860,7 +868,15 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
         async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
-        async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));   // clamp: a stale register must not fault
+        // clamp: a stale register must not fault
+#if defined(SH_FORCE_WT)
+        async_load_sc1(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+#elif defined(SH_NO_SC1)
+        async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+#else
+        if constexpr (FUSED) async_load_sc1(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+        else async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+#endif
       }
     };
     auto wait8 = [&](v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K], uint32_t (&g)[P2S_K]) {
@@ -898,6 +914,7 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
         g[0][k] = (gsrc + cur.pstart / 4)[min(0 * P2S_Q + k * P2S_LD + tid, max(cur.n / 4, 1) - 1)];
         g[1][k] = (gsrc + b1.pstart / 4)[min((1 % P2S_NS) * P2S_Q + k * P2S_LD + tid, max(b1.n / 4, 1) - 1)];
       }
+      ensure(cur);
       issue_ps(cur, 0, g[0], p[0], sl[0]);
       issue_gs(bin_of(2), 2 % P2S_NS, g[0]);
       issue_ps(bin_of(1), 1 % P2S_NS, g[1], p[1], sl[1]);
@@ -907,11 +924,12 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
         uint32_t *img = prod[j & 1];
 #pragma unroll
         for (int s = 0; s < P2S_NS; s++) {
-          constexpr int dummy = 0; (void)dummy;
           const int a = s & 1;
           wait8(p[a], sl[a], g[a]);                        // P/S(q) and gsrc(q+2) have landed
           scatter(img, cur, s, p[a], sl[a]);
           issue_gs(bin_of(s + 3), (s + 3) % P2S_NS, g[a ^ 1]);        // gsrc(q+3)
+          if ((s + 2) % P2S_NS == 0)
+            ensure(bin_of(s + 2));                         // first P load of the next bin
           issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
           if (s == P2S_NS / 2 - 1)
             lds_barrier();   // MID
@@ -926,13 +944,23 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
         lds_barrier();   // MID2
       lds_barrier();     // END
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave moves on
   } else {
     // ------------------------------------------------------------------ reducers
     const int rt = tid - P2S_LD;
     RowBin prev = bin_at(0);
+    int pub = -1;   // FUSED: the slab lane rt == 64 has published as written
     for (int j = 0; j <= nb; j++) {
       const RowBin cur = bin_at(j);
+      // FUSED, one lane: is the slab of the bin after next written?  (asked here, looked at after the reduction)
+      int want = -1;
+      bool open = false;
+      if constexpr (FUSED) {
+        if (rt == 64 && j + 2 < nb) {
+          want = bins[b0 + (j + 2) * stride].slab;
+          if (want > pub) open = need[2 * want] == 0 || gate_is_open(gates + want * GATE_WORDS);
+        }
+      }
       // row offsets of the bin being streamed now (needed by the next reduction)
       uint32_t rr[P2S_RPU];
       if (j < nb) {
@@ -957,8 +985,8 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
       } else {
         // nothing to reduce yet (the loaders are filling the first image): add up the heavy rows'
         // phase-1 partials meanwhile, one row per wave
-        for (int h = (int)blockIdx.x * (P2S_RD / 64) + (rt >> 6); h < n_heavy; h += G * (P2S_RD / 64))
-          heavy_row_by_wave<SR>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
+        for (int h = heavy_first + (rt >> 6); h < n_heavy; h += heavy_stride)
+          heavy_row_by_wave<SR, false>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
         lds_barrier();   // MID
         if (staged)
           lds_barrier(); // MID2
@@ -974,9 +1002,227 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
           }
       }
       lds_barrier();     // END
+      if constexpr (FUSED) {
+        if (rt == 64 && want > pub && open) {
+          *(volatile int32_t *)&L.ready_slab = want;   // (loaders look at it at their step 2 of the next bin)
+          pub = want;
+        }
+        // Every loader wave has scattered bin j: all of its P loads have landed, the ring slot may go once
+        // all of the slab's bins said so.  Arrival from a reducer lane (in a loader wave the atomic would sit
+        // in the hand-counted vmcnt window), and its outcome is looked at right away: a worker must never
+        // block -- its loaders may, on the next slab -- while the flag it owes is unset.
+        if (rt == 0 && j < nb) {
+          uint32_t *g = gates + (n_slabs + cur.slab) * GATE_WORDS;
+          const uint32_t before = gate_arrive(g);
+          SH_STAT(if (slab_t && (int32_t)before + 1 == need[2 * cur.slab + 1]) slab_t[2 * cur.slab + 1] = __builtin_amdgcn_s_memrealtime();)
+          gate_finish(g, before, (uint32_t)need[2 * cur.slab + 1]);
+        }
+      }
       prev = cur;
     }
   }
+}
+
+template <class SR>
+__global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
+    const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
+    const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
+    const uint32_t *__restrict__ gsrc, const LongRow *__restrict__ heavy_rows, int32_t n_heavy,
+    const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
+    typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
+  __shared__ P2Lds L;
+  const int G = gridDim.x;
+  // consecutive bins on one XCD: workgroups are dealt round-robin over the 8 XCDs (blocks w and
+  // w+8 share one) and neighbouring bins own neighbouring pieces of every tile in P, so the 128-B
+  // lines at piece boundaries are wanted by both (speed only; any placement is correct)
+  const int b0 = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  if (b0 >= n_bins)
+    return;
+  const int nb = (n_bins - b0 + G - 1) / G;    // bins of this workgroup: b0, b0+G, ...
+  tiled_phase2_run<SR, false>(L, bins, b0, nb, G, row_ptr, P, last_group, pslot, gsrc, heavy_rows, n_heavy,
+                              (int)blockIdx.x * (P2S_RD / 64), G * (P2S_RD / 64), heavy_partial, y, alpha, beta,
+                              use_y_i != 0, out, st, nullptr, 0, nullptr, nullptr);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The tiled plan as ONE persistent launch (default).  One 1024-thread workgroup per CU; workgroups
+// are split into two roles that run side by side on different CUs:
+//   phase-1 workers  claim chunks from per-XCD queues (slab-major; chunk of tile t in queue t % 8 so
+//                    that an XCD's L2 only stages its own eighth of x), stage the x tile, write the
+//                    slab's products into its slot of the P ring (write-through);
+//   phase-2 workers  walk the row bins in order (wave-specialised loaders/reducers as above) and
+//                    wait at each slab boundary until all of the slab's chunks have signalled.
+// A product is therefore re-read a few tens of microseconds after it was written and its line is
+// overwritten `ring` slabs later: P lives in the 256 MiB Infinity Cache and never costs HBM time
+// (profiles/r02_lab_slab_mall_ring_microbench.log: 7.9 instead of 5.3 TB/s for the same bytes).
+// Dependencies, all through gates in `ctl` (zeroed before every launch):
+//   chunk of slab s   needs gate read(s - ring): all bins of that slab consumed, ring slot free
+//   bin of slab s     needs gate written(s): all chunks of the slab stored
+//   heavy rows        need gate heavy: all heavy chunks stored
+// Both queues are claimed in slab order, so every wait is for items that running workgroups
+// already hold: no cycle as long as all workgroups are resident (grid == CU count, one per CU by
+// LDS).  Every spin is bounded (gate_wait) and reports through a host-visible error word.
+// When their own work is done, workers of both roles drain the heavy-chunk queue (phase-1 work
+// that touches no slab) and then add up the heavy rows' partials.
+struct FusedDev {
+  const TileChunk *qchunks;      // 8 light-chunk queues, concatenated; queue q = [lq0[q], lq0[q+1])
+  const int32_t *lq0;            // [9]
+  const TileChunk *hchunks;      // heavy chunks
+  int32_t n_hchunks, cols;
+  const void *tval;              // raw value words or value codes
+  const uint32_t *vdict;
+  const uint16_t *tcol;
+  const uint32_t *gdest;
+  const uint32_t *x;
+  uint32_t *P;
+  uint32_t p_bytes;
+  int32_t last_group;
+  uint32_t *partial;
+  const RowBin *bins;
+  const int32_t *lrp;
+  const uint16_t *pslot;
+  const uint32_t *gsrc;
+  const LongRow *heavy_rows;
+  const int32_t *need;           // [2 * n_slabs]: {light chunks, bins} of each slab
+  uint32_t *ctl;
+  uint32_t *err;                 // host-visible word: set when a bounded spin gave up
+  uint64_t *stats;               // SH_STATS builds: 8 words per workgroup
+  int32_t dbg;                   // SH_STATS builds: 1 = phase-1 workers only signal, 2 = phase-2 workers only signal
+  int32_t n_bins, n_heavy, n_slabs, ring, n2;
+};
+// ctl words: queue head of slot q at q * 16 (64 B apart), then
+constexpr int CTL_HHEAD = 128, CTL_GATES = 192;   // gates: heavy, written(0..S-1), read(0..S-1)
+
+template <class SR, int VC>
+__global__ __launch_bounds__(P2S_BS) void spmv_tiled_fused(
+    const FusedDev D, const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
+    int use_y_i, uint32_t *__restrict__ out, StepDev st) {
+  static_assert(P2S_BS == TBS, "both roles use the whole workgroup");
+  __shared__ union { P2Lds p2; uint32_t xs[TCOLS + 4]; } U;
+  __shared__ uint32_t ds[VC ? VDICT : 1];
+  __shared__ int32_t claim;
+  const int tid = threadIdx.x;
+  const int slot = blockIdx.x & 7, k = blockIdx.x >> 3;
+  uint32_t *const ctl = D.ctl;
+  uint32_t *const gate_heavy = ctl + CTL_GATES, *const gates = gate_heavy + GATE_WORDS, *const err = D.err;
+  const bool use_y = use_y_i != 0;
+  bool gave_up = false;
+  SH_STAT(uint64_t st_wait = 0, st_items = 0, st_heavy = 0; const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime();)
+  SH_STAT(__shared__ uint64_t st_p2wait;)
+
+  // Queues are claimed one ticket ahead: the atomic for the NEXT item flies while the current one is
+  // processed (a returning atomic costs 1-3 us under load).  Workgroup-uniform result, -1 = exhausted.
+  uint32_t ticket = 0;   // thread 0 only
+  auto claim_first = [&](uint32_t *head) {
+    if (tid == 0) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto claim_next = [&](uint32_t *head, int32_t n) -> int32_t {
+    if (tid == 0) {
+      claim = ticket < (uint32_t)n ? (int32_t)ticket : -1;
+      if (ticket < (uint32_t)n) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int32_t c = claim;
+    __syncthreads();   // (also: every wave is done with the LDS of the previous item)
+    return c;
+  };
+  // A chunk's completion is signalled one chunk late, from inside the next chunk (see tiled_phase1_chunk),
+  // or by flush() when the worker leaves phase-1 work: nobody waits out a store drain per chunk.
+  int pend = -2;          // slab of the chunk whose signal is pending (-1: heavy, -2: none); workgroup-uniform
+  int ring_free = D.ring - 1;   // slabs up to this one are known to have a free ring slot; workgroup-uniform
+  // arrival of a finished chunk at its gate (thread 0); the outcome is looked at later (finish_arrival)
+  uint32_t arr_before = 0;
+  int arr_slab = -2;
+  auto gate_of = [&](int slab) { return slab >= 0 ? gates + slab * GATE_WORDS : gate_heavy; };
+  auto need_of = [&](int slab) { return (uint32_t)(slab >= 0 ? D.need[2 * slab] : D.n_hchunks); };
+  auto arrive = [&](int slab) {
+    arr_before = gate_arrive(gate_of(slab));
+    arr_slab = slab;
+  };
+  auto finish_arrival = [&]() {
+    if (arr_slab != -2) {
+      SH_STAT(if (D.stats && arr_slab >= 0 && arr_before + 1 == need_of(arr_slab)) D.stats[4096 + 2 * arr_slab] = __builtin_amdgcn_s_memrealtime();)
+      gate_finish(gate_of(arr_slab), arr_before, need_of(arr_slab));
+      arr_slab = -2;
+    }
+  };
+  auto flush = [&]() {
+    if (pend != -2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0) { finish_arrival(); arrive(pend); finish_arrival(); }
+      pend = -2;
+    }
+  };
+  auto run_chunk = [&](const TileChunk ch) {
+    if (ch.slab > ring_free) {   // the ring slot must have been read completely (checked once per slab)
+      flush();                   // (what is waited for may itself be waiting for this worker's pending signal)
+      if (tid == 0)
+        gate_wait(gates + (D.n_slabs + ch.slab - D.ring) * GATE_WORDS, err, gave_up SH_STAT(, &st_wait));
+      ring_free = ch.slab;
+    }
+    __syncthreads();
+    const int prev = pend;
+    // (the previous chunk's arrival is issued behind this chunk's staging barrier and looked at after the
+    // chunk: the returning atomic never stalls the stream)
+    auto staged = [&]() { if (tid == 0 && prev != -2) { finish_arrival(); arrive(prev); } };
+    SH_STAT(if (D.dbg & 1) { staged(); pend = ch.slab; return; })
+#ifdef SH_NO_SC1   // tuning builds: plain stores (results invalid; timing only)
+    tiled_phase1_chunk<SR, VC, false>(ch, U.xs, ds, D.tval, D.vdict, D.tcol, D.gdest, D.x, D.cols, D.P, D.p_bytes, D.partial, staged);
+#else
+    tiled_phase1_chunk<SR, VC, true>(ch, U.xs, ds, D.tval, D.vdict, D.tcol, D.gdest, D.x, D.cols, D.P, D.p_bytes, D.partial, staged);
+#endif
+    if (tid == 0) finish_arrival();
+    pend = ch.slab;
+  };
+
+  if (k < D.n2) {
+    // ---------------------------------------------------------------- phase-2 worker
+    const int v = slot * D.n2 + k, N2 = 8 * D.n2;   // consecutive bins on one XCD (see spmv_tiled_phase2s)
+    if (v < D.n_bins) {
+      const int nb = (D.n_bins - v + N2 - 1) / N2;
+      SH_STAT(uint64_t w = 0;)
+      SH_STAT(if (D.dbg & 2) { if (tid == 0) for (int j = 0; j < nb; j++) { const int sl = D.bins[v + j * N2].slab; uint32_t *g = gates + (D.n_slabs + sl) * GATE_WORDS;
+                                 gate_finish(g, gate_arrive(g), (uint32_t)D.need[2 * sl + 1]); } } else)
+      tiled_phase2_run<SR, true>(U.p2, D.bins, v, nb, N2, D.lrp, D.P, D.last_group, D.pslot, D.gsrc, nullptr, 0, 0, 1,
+                                 nullptr, y, alpha, beta, use_y, out, st, gates, D.n_slabs, D.need, err SH_STAT(, &w, D.stats ? D.stats + 4096 : nullptr));
+      SH_STAT(if (tid == 0) st_p2wait = w; __syncthreads(); st_wait = st_p2wait; st_items = nb;)
+    }
+  } else {
+    // ---------------------------------------------------------------- phase-1 worker
+    for (int dq = 0; dq < 8; dq++) {   // its own XCD's queue first, then the others'
+      const int q = (slot + dq) & 7;
+      const int32_t q0 = D.lq0[q], n = D.lq0[q + 1] - q0;
+      claim_first(ctl + q * 16);
+      for (;;) {
+        const int32_t c = claim_next(ctl + q * 16, n);
+        if (c < 0) break;
+        run_chunk(D.qchunks[q0 + c]);
+        SH_STAT(st_items++;)
+      }
+    }
+  }
+  SH_STAT(const uint64_t st_t1 = __builtin_amdgcn_s_memrealtime();)
+  // ------------------------------------------------------------------ both: heavy chunks, then heavy rows
+  claim_first(ctl + CTL_HHEAD);
+  for (;;) {
+    const int32_t c = claim_next(ctl + CTL_HHEAD, D.n_hchunks);
+    if (c < 0) break;
+    run_chunk(D.hchunks[c]);
+    SH_STAT(st_heavy++;)
+  }
+  flush();
+  SH_STAT(const uint64_t st_t2 = __builtin_amdgcn_s_memrealtime();)
+  if (D.n_heavy > 0) {
+    if (tid == 0 && D.n_hchunks > 0)
+      gate_wait(gate_heavy, err, gave_up);
+    __syncthreads();
+    for (int h = (int)blockIdx.x * (P2S_BS / 64) + (tid >> 6); h < D.n_heavy; h += (int)gridDim.x * (P2S_BS / 64))
+      heavy_row_by_wave<SR, true>(D.heavy_rows[h], D.partial, tid & 63, y, alpha, beta, use_y, out, st);
+  }
+  SH_STAT(if (tid == 0 && D.stats) { uint64_t *S = D.stats + (size_t)blockIdx.x * 8; S[0] = k < D.n2; S[1] = st_items; S[2] = st_t0;
+            S[3] = st_t1; S[4] = st_t2; S[5] = st_wait; S[6] = st_heavy; S[7] = __builtin_amdgcn_s_memrealtime(); })
 }
 
 } // namespace sh

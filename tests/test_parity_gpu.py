@@ -372,20 +372,37 @@ def test_upload_times_both_plans_for_large_matrices(eng, plan, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])
-def test_classic_phase2_kernel_still_matches(eng, cases, name, plan, monkeypatch):
-    """SH_P2=classic keeps the previous phase-2 kernel (+ the stand-alone heavy-row fixup on a side stream)
-    selectable for A/B runs; it must stay correct."""
+@pytest.mark.parametrize("slab_mb,ring,fused", [("0.5", "2", "1"), ("1", "3", "1"), ("0.5", "64", "1"),
+                                                ("0.0625", "2", "0"), ("0.25", "3", "0"), ("0.0625", "1", "0")])
+def test_slab_ring_matches(eng, cases, name, plan, slab_mb, ring, fused, monkeypatch):
+    """The tiled plan cuts the row bins into slabs whose products share a small ring of P slots (phase 2 of
+    a slab runs right behind its phase 1).  Tiny slabs force many slabs and slot reuse on small inputs; a
+    ring at least as long as the slab count is the linear layout.  Two different x in a row: a stale
+    product left in a reused slot by the previous launch would show."""
     if plan != "tiled":
-        pytest.skip("phase 2 belongs to the tiled plan")
-    monkeypatch.setenv("SH_P2", "classic")
+        pytest.skip("slabs belong to the tiled plan")
+    monkeypatch.setenv("SH_SLAB_MB", slab_mb)
+    monkeypatch.setenv("SH_RING", ring)
+    monkeypatch.setenv("SH_FUSED", fused)   # one persistent launch with in-launch hand-offs / one launch per slab and phase
+    monkeypatch.setenv("SH_N2", "1")        # (fused: 8 phase-2 workers, so that slabs of 8 bins qualify)
     rp, ci, va, n = cases[name]
-    xm = (1 + np.arange(n) % 7).astype(np.float32)
     ym = (np.arange(n) % 5).astype(np.float32)
-    got = run_spmv(eng, O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)
-    np.testing.assert_array_equal(bits(got), bits(O.kernel(O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)))
+    A = eng.upload_csr(n, n, rp, ci, np.ascontiguousarray(va, np.float32))
+    assert "slabs=" in A.describe() and (" fused" in A.describe()) == (fused == "1"), A.describe()
+    yv, out = eng.vector(ym), eng.alloc(n).fill(0)
+    for k in (7, 5, 11):
+        xm = (1 + np.arange(n) % k).astype(np.float32)
+        xv = eng.vector(xm)
+        eng.spmv(O.PLUS_TIMES_F32, A, xv, yv, 2.0, 0.5, out)
+        np.testing.assert_array_equal(bits(out.download(np.float32)), bits(O.kernel(O.PLUS_TIMES_F32, rp, ci, va, xm, ym, 2.0, 0.5)))
+        xv.free()
     x0 = O.initial_vector(O.MIN_PLUS_F32, n)
-    got = run_spmv(eng, O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)
-    np.testing.assert_array_equal(bits(got), bits(O.kernel(O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)))
+    xv = eng.vector(x0)
+    eng.spmv(O.MIN_PLUS_F32, A, xv, xv, 0.0, 0.0, out)
+    np.testing.assert_array_equal(bits(out.download(np.float32)), bits(O.kernel(O.MIN_PLUS_F32, rp, ci, va, x0, x0, 0.0, 0.0)))
+    for v in (xv, yv, out):
+        v.free()
+    A.free()
 
 
 def test_rectangular_and_wide_matrices(eng):

@@ -48,7 +48,19 @@ __global__ __launch_bounds__(NT) void wr_loop(float4 *p, size_t n4, int reps) {
 
 // One persistent launch.  Slab s of P occupies P[(s * slab4) % ring4 ...).  Per inner iteration a
 // thread reads mr float4 of M, writes 2 float4 of P (slab s) and reads 2 float4 of P (slab s-1).
-template <int MR, bool DO_W, bool DO_R>
+// SC1: P goes through write-through (sc1) stores and sc1 loads, as an in-launch hand-off needs
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16(float4 *p, float4 v, bool sc1) {
+  if (sc1) { const v4f w = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory"); }
+  else *p = v;
+}
+// (both loads of an iteration fly together; one wait behind the second)
+__device__ __forceinline__ void ld16x2(const float4 *p, const float4 *q, float4 &a, float4 &b) {
+  v4f va, vb;
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(va), "=&v"(vb) : "v"(p), "v"(q) : "memory");
+  a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w);
+}
+template <int MR, bool DO_W, bool DO_R, bool SC1 = false>
 __global__ __launch_bounds__(NT) void slab_loop(const float4 *M, float4 *P, size_t m4_per_slab, size_t slab4, size_t ring4,
                                                 int s0, int s1, float *sink) {
   float a = 0;
@@ -65,12 +77,12 @@ __global__ __launch_bounds__(NT) void slab_loop(const float4 *M, float4 *P, size
       float4 v[MR > 0 ? MR : 1], r0 = make_float4(0, 0, 0, 0), r1 = r0;
 #pragma unroll
       for (int k = 0; k < MR; k++) v[k] = (im + k * NT < mper) ? m[im + k * NT] : make_float4(0, 0, 0, 0);
-      if (rd) { r0 = pr[ip]; r1 = pr[ip + NT]; }
+      if (rd) { if constexpr (SC1) { ld16x2(pr + ip, pr + ip + NT, r0, r1); } else { r0 = pr[ip]; r1 = pr[ip + NT]; } }
       float t = 0;
       v[0] = MR > 0 ? v[0] : make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int k = 0; k < MR; k++) t += v[k].x;
-      if constexpr (DO_W) { pw[ip] = make_float4(t, t, t, t); pw[ip + NT] = make_float4(t, v[0].y, t, t); }
+      if constexpr (DO_W) { st16(pw + ip, make_float4(t, t, t, t), SC1); st16(pw + ip + NT, make_float4(t, v[0].y, t, t), SC1); }
       a += r0.x + r1.y + t;
     }
   }
@@ -121,6 +133,19 @@ int main() {
       float t = timeit([&] {
         slab_loop<3, true, true><<<256, NT>>>((const float4 *)M, (float4 *)P, m4, slab4, ring4, 0, S, sink);
         slab_loop<0, false, true><<<256, NT>>>((const float4 *)M, (float4 *)P, 0, slab4, ring4, S - 1, S, sink);
+      });
+      printf("  %2d slabs of %5.1f MB P, %s: %7.1f us  %5.2f TB/s\n", S, Ptot / 1048576.0 / S, ring ? "ring of 2 slabs  " : "linear addresses ",
+             t * 1e3, (Ptot * 2 + Mtot) * 1e-9 / t);
+    }
+  }
+  printf("part 3: the same with write-through (sc1) P stores and sc1 P loads\n");
+  for (int S : {8, 16, 32}) {
+    const size_t slab4 = Ptot / 16 / S, m4 = Mtot / 16 / S;
+    for (int ring : {0, 1}) {
+      const size_t ring4 = ring ? 2 * slab4 : slab4 * S;
+      float t = timeit([&] {
+        slab_loop<3, true, true, true><<<256, NT>>>((const float4 *)M, (float4 *)P, m4, slab4, ring4, 0, S, sink);
+        slab_loop<0, false, true, true><<<256, NT>>>((const float4 *)M, (float4 *)P, 0, slab4, ring4, S - 1, S, sink);
       });
       printf("  %2d slabs of %5.1f MB P, %s: %7.1f us  %5.2f TB/s\n", S, Ptot / 1048576.0 / S, ring ? "ring of 2 slabs  " : "linear addresses ",
              t * 1e3, (Ptot * 2 + Mtot) * 1e-9 / t);

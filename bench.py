@@ -7,16 +7,20 @@ matrix, inputs resident in HBM.  Default workload = BASELINE.json configs[4],
 the one the target is quoted on: power-law 10 M rows / 200 M non-zeros
 (SURVEY.md 8d generator, seed 0x5EED1000), which fits one GPU.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the SAME matrix
-is row-sharded into nnz-balanced contiguous row ranges (strong scaling); x is
-replicated; single-shot SpMV needs no collective (each rank owns its slice of y).
+Multi-GPU (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through
+torch.distributed.run when no launcher did): the SAME matrix is row-sharded into
+work-balanced contiguous row ranges (strong scaling); x is replicated; single-shot
+SpMV needs no collective (each rank owns its slice of y).
 value = 2 * nnz_total * K / max-over-ranks wall time.
 
 Prints ONE JSON line on rank 0 with the driver's contract keys plus
   roofline     : algorithmic bytes of this rank's launch / its average device
                  time (HIP events on the launch stream), vs 8 TB/s HBM peak
-  cpu_baseline : the oracle's single-thread restatement of the reference gold
-                 dot loop (inc/spmv_gold.h:17-26) timed on this host (N=1 only)
+  cpu_baseline : the oracle's restatement of the reference gold dot loop
+                 (inc/spmv_gold.h:17-26) timed on this host (N=1 only): single thread
+                 (the reference is single-threaded) and, under all_cores, row-parallel
+                 on every host core
+  frac_raw_values : the same matrix with value coding off (general fp32 data)
 """
 import argparse
 import json
@@ -32,16 +36,32 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-# HBM bytes per SpMV launch measured in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
-# WRITE_SIZE, MI355X_MICROARCH.md "HBM"); PMC cannot be collected inside this process.  Keyed by
-# (workload, plan, n_gpus); anything else reports null.  Provenance: profiles/r01_pmc_tiled_v6_powerlaw.txt
-MEASURED_TRAFFIC_BYTES = {("powerlaw-10M-200M", "tiled", 1): 2328464384}
+# HBM bytes per SpMV launch come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE x2 correction +
+# WRITE_SIZE, MI355X_MICROARCH.md "HBM"; tools/pmc.sh): PMC cannot be collected inside this process.
+# profiles/measured_traffic.json holds one record per (workload, device layout, n_gpus); a run whose
+# layout string has no record reports null -- the figure never outlives the kernels it was measured on.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "measured_traffic.json")
+
+
+def measured_traffic(workload, layout, n_gpus):
+    try:
+        recs = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, "no profiles/measured_traffic.json"
+    for r in recs:
+        if (r["workload"], r["layout"], r["n_gpus"]) == (workload, layout, n_gpus):
+            return r["bytes"], r["source"]
+    return None, "no rocprofv3 --pmc record for this workload / layout in profiles/measured_traffic.json"
 
 WORKLOADS = {
     # name: (kind, rows, nnz, description)
     "powerlaw-10M-200M": ("powerlaw", 10_000_000, 200_000_000,
                           "power-law rows P(d)~d^-2.1 on [1,1e6], uniform columns, 10M x 10M, 200M nnz, seed 0x5EED1000"),
     "rmat-23": ("rmat", 1 << 23, 16 << 23, "Graph500 R-MAT scale 23, edge factor 16, permuted ids, seed 0x5EED0023"),
+    # NOT a BASELINE config: the same R-MAT without the vertex permutation, i.e. a graph whose columns are
+    # as local as R-MAT's quadrant recursion makes them -- what the plans reach when there IS column locality
+    "rmat-23-unpermuted": ("rmat-local", 1 << 23, 16 << 23,
+                           "Graph500 R-MAT scale 23, edge factor 16, ids NOT permuted (column locality), seed 0x5EED0023"),
     "scircuit-like": ("scircuit", 170_998, 958_936, "scircuit-shaped stand-in, seed 0x5EED5C1C"),
 }
 
@@ -54,13 +74,49 @@ def make_workload(name, rows=None, nnz=None):
         rp, ci, va = H.powerlaw(r, z)
         if rows or nnz:
             desc += f" [overridden to {r} rows / {z} nnz]"
-    elif kind == "rmat":
+    elif kind in ("rmat", "rmat-local"):
         scale = int(np.log2(rows)) if rows else 23
-        rp, ci, va = H.rmat(scale)
+        rp, ci, va = H.rmat(scale, permute=(kind == "rmat"))
         r, z = 1 << scale, int(rp[-1])
     else:
         rp, ci, va = H.scircuit_like()
     return rp, ci, va, r, desc
+
+
+def usable_host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands a one-GPU job 16 of its 256 cores; more threads than that only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU) BEFORE this process has imported torch or touched HIP -- a process
+    that has initialised the GPU must never exec -- relay their output (rank 0 prints the JSON line) and
+    exit with their return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -76,7 +132,11 @@ def main():
                     help="skip the extra timing of the same matrix with value coding off (N=1 only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (corrected); echoed into roofline.traffic")
+    ap.add_argument("--real-values", action="store_true",
+                    help="replace the integer weights by non-integer floats (~1e6 distinct values: no value coding possible)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -104,6 +164,10 @@ def main():
 
     t_gen = time.time()
     rp, ci, va, n, desc = make_workload(args.workload, args.rows, args.nnz)
+    if args.real_values:
+        # weights w + (k mod 997) / 1024: exactly representable, > 256 distinct values, sums exact in float64
+        va = (va + (np.arange(len(va), dtype=np.int64) % 997).astype(np.float32) / np.float32(1024)).astype(np.float32)
+        desc += " [weights made non-integer: w + (k mod 997)/1024]"
     nnz_total = int(rp[-1])
     t_gen = time.time() - t_gen
 
@@ -162,10 +226,28 @@ def main():
             O.gold_dot(rp, ci, va, x_host, 1.0, out=gold)
             times.append(time.perf_counter() - tc)
         tmed = sorted(times)[1]
+        # the same loop row-parallel on every host core this process may use (OpenMP, rows still summed sequentially)
+        ncores = usable_host_cores()
+        par = np.empty(n, np.float32)
+        ptimes, used = [], 1
+        for _ in range(3):
+            tc = time.perf_counter()
+            _, used = O.gold_dot_all_cores(rp, ci, va, x_host, 1.0, out=par, threads=ncores)
+            ptimes.append(time.perf_counter() - tc)
+        pmed = sorted(ptimes)[1]
+        model = ""
+        try:
+            model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
         cpu = {"value": round(2.0 * nnz_total / tmed / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
                "sample": f"full {args.workload} matrix ({nnz_total} nnz), median of 3 single-thread runs of the "
                          f"gold dot loop restatement (oracle_gold_dot_f32), {tmed:.3f} s each",
-               "host_cpus": os.cpu_count()}
+               "all_cores": {"value": round(2.0 * nnz_total / pmed / 1e9, 4), "unit": "GFLOP/s", "cores": used,
+                             "sample": f"the same loop, rows dealt to {used} OpenMP threads (oracle_gold_dot_f32_omp), "
+                                       f"median of 3, {pmed:.3f} s each",
+                             "same_bits_as_single_thread": bool(np.array_equal(par.view(np.uint32), gold.view(np.uint32)))},
+               "host_cpus": os.cpu_count(), "cpu_model": model}
         want = gold
     else:
         want = O.gold_dot(s_rp, s_ci, s_va, x_host, 1.0)
@@ -194,15 +276,7 @@ def main():
     # matrix with more than 256 distinct values gets; NOT the reported value
     ablation = None
     if rank == 0 and world == 1 and not args.no_ablation and "values=dict" in A.describe():
-        prev_vc = os.environ.get("SH_VALCODE")
-        os.environ["SH_VALCODE"] = "off"
-        try:
-            A_raw = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va)
-        finally:
-            if prev_vc is None:
-                os.environ.pop("SH_VALCODE", None)
-            else:
-                os.environ["SH_VALCODE"] = prev_vc
+        A_raw = eng.upload_csr(s_rows, n, s_rp, s_ci, s_va, value_coding=-1)
         out2_t = torch.zeros_like(out_t)
         out2 = eng.wrap(out2_t.data_ptr(), s_rows)
         for _ in range(3):
@@ -215,7 +289,8 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         raw_ms = e0.elapsed_time(e1) / 20
-        ablation = {"layout": A_raw.describe(), "ms_per_step": round(raw_ms, 6),
+        raw_traffic, raw_src = measured_traffic(args.workload, A_raw.describe(), world)
+        ablation = {"layout": A_raw.describe(), "ms_per_step": round(raw_ms, 6), "traffic": raw_traffic, "traffic_source": raw_src,
                     "frac_of_peak": round(A.algorithmic_bytes(reads_y=False) / (raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "same_result_bits": bool(torch.equal(out2_t.view(torch.int32), out_t.view(torch.int32))),
                     "note": "value coding off (SH_VALCODE=off): what a matrix with more than 256 distinct values runs at"}
@@ -223,6 +298,10 @@ def main():
 
     alg_bytes = A.algorithmic_bytes(reads_y=False)
     achieved = alg_bytes / (dev_ms_per_launch * 1e-3) / 1e9
+    layout = A.describe()
+    traffic, traffic_src = measured_traffic(args.workload, layout, world) if not (args.rows or args.nnz or args.real_values) else (None, "non-headline run")
+    if args.traffic_bytes is not None:
+        traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     result = {
         "metric": "spmv_gflops", "value": round(2.0 * nnz_total * args.steps / wall / 1e9, 3), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,18 +311,20 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "x": "1 + (i mod 7)", "sharding": f"{world} work-balanced contiguous row ranges, x replicated"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": (args.traffic_bytes if args.traffic_bytes is not None else
-                                 (None if (args.rows or args.nnz) else
-                                  MEASURED_TRAFFIC_BYTES.get((args.workload, A.plan()[0], world)))),
-                     "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_tiled_v6_powerlaw.txt",
-                     "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)" if A.plan()[0] == "tiled"
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": (("sh::spmv_tiled_fused<PlusTimesF32> (one persistent launch)" if " fused" in layout else
+                                 "sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)") if A.plan()[0] == "tiled"
                                 else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
                      "rank": rank, "rank_nnz": s_nnz},
         "cpu_baseline": cpu,
+        # the same matrix with value coding off = what a matrix with more than 256 distinct values runs at;
+        # first-class because the headline layout (four-bit codes) owes its stream size to the synthetic weights 1..16
+        "frac_raw_values": None if ablation is None else ablation["frac_of_peak"],
+        "ms_per_step_raw_values": None if ablation is None else ablation["ms_per_step"],
         "ablation_raw_values": ablation,
         "parity": parity,
-        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": A.describe()},
+        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": layout},
         "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,
     }
     if rehearsal:

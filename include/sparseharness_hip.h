@@ -64,10 +64,10 @@ typedef enum {
 
 /* Launch geometry handed down from the run-file: replaces class Run
  * (inc/run.h:9-32) as consumed by Harness::executeKernel
- * (inc/harness.h:153-158).  The native kernels derive their grid from the
- * matrix schedule; local[0] (64..1024, multiple of 64) is honoured as the
- * workgroup size where the kernel allows it, everything else is recorded and
- * ignored.  May be NULL. */
+ * (inc/harness.h:153-158).  The native kernels derive grid AND workgroup size
+ * from the matrix schedule built at upload; the run's numbers are recorded by
+ * the caller (they appear in the SQL row) and do not shape the launch.
+ * May be NULL. */
 typedef struct sh_launch {
   uint64_t global[3];
   uint64_t local[3];
@@ -107,6 +107,30 @@ const char *sh_last_error(const sh_engine *e);
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
                   const int32_t *row_ptr, const int32_t *col_idx, const void *val,
                   sh_csr **out);
+/* The same with explicit plan options instead of the environment.  sh_csr_upload
+ * is sh_csr_upload_ex with sh_plan_options_from_env(): the SH_* variables are
+ * read once per upload, never at launch time.  Zero-initialise, then call
+ * sh_plan_options_default() and change what you need. */
+typedef struct sh_plan_options {
+  int32_t plan;            /* 0 auto (size rule, then timing when the columns are local), 1 stream, 2 tiled   [SH_PLAN]     */
+  int32_t autotune;        /* 1: time both plans at upload when the rule says tiled and the columns are local [SH_AUTOTUNE] */
+  int32_t value_coding;    /* 0 auto (4-bit / 8-bit dictionary codes when the data allows), 8: one-byte codes at most,
+                              -1 off (raw 4-byte values)                                                      [SH_VALCODE]  */
+  int32_t build_threads;   /* host threads of the layout build, 0 = min(hardware, 16)                         [SH_BUILD_THREADS] */
+  int32_t heavy_per_tile;  /* rows averaging >= this many entries per column tile are pre-reduced in phase 1  [SH_HEAVY_PER_TILE] */
+  int32_t chunk;           /* entries per phase-1 work item                                                   [SH_CHUNK]    */
+  int32_t xcd_order;       /* 1: phase-1 work items ordered so that an XCD stages only its eighth of x        [SH_XCD_ORDER] */
+  int32_t fused;           /* 1: the tiled plan as ONE persistent launch with in-launch slab hand-offs
+                              (experimental: measured slower than two launches)                    [SH_FUSED]    */
+  int32_t ring;            /* P ring slots (slabs reuse them; >= slab count: no reuse)                        [SH_RING]     */
+  int32_t n2;              /* fused: phase-2 workgroups per XCD (of CUs/8)                                    [SH_N2]       */
+  double slab_mb;          /* MiB of products per slab; huge = one slab                                       [SH_SLAB_MB]  */
+} sh_plan_options;
+void sh_plan_options_default(sh_plan_options *o);
+void sh_plan_options_from_env(sh_plan_options *o);
+int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
+                     const int32_t *row_ptr, const int32_t *col_idx, const void *val,
+                     const sh_plan_options *opt, sh_csr **out);
 int sh_csr_free(sh_engine *e, sh_csr *m);
 int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
 /* Algorithmic bytes of one SpMV over this matrix:

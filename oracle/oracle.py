@@ -92,6 +92,20 @@ def gold_dot(row_ptr, col_idx, val, x, alpha=1.0, out=None):
     return out
 
 
+def gold_dot_all_cores(row_ptr, col_idx, val, x, alpha=1.0, out=None, threads=None):
+    """The same dot loop row-parallel under OpenMP (rows still summed sequentially: same bits).
+    Returns (result, threads that ran)."""
+    import os
+    rows = len(row_ptr) - 1
+    if out is None:
+        out = np.empty(rows, np.float32)
+    fn = lib().oracle_gold_dot_f32_omp
+    fn.restype = C.c_int
+    used = fn(C.c_int64(rows), _p(row_ptr), _p(col_idx), _p(val), _p(x), C.c_float(alpha), _p(out),
+              C.c_int(threads or os.cpu_count() or 1))
+    return out, int(used)
+
+
 def kernel(semiring, row_ptr, col_idx, val, x, y, alpha, beta, vlength=None):
     """One launch of the Lift glb-sdp kernel semantics for `semiring`."""
     dt = elem_dtype(semiring)

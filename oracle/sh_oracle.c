@@ -16,6 +16,9 @@
  */
 #include <ctype.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -236,6 +239,35 @@ void oracle_gold_dot_f32(int64_t rows, const int32_t *row_ptr,
       acc += alpha * (x[col_idx[j]] * val[j]);
     result[i] = acc;
   }
+}
+
+/* The same loop, rows handed out to `threads` OpenMP threads (each row is still summed sequentially in
+ * stored order, so the result is bit-identical to the single-thread loop): bench.py's all-cores
+ * cpu_baseline ("plus an OpenMP row-parallel variant on all available cores").  Returns
+ * the number of threads that actually ran. */
+int oracle_gold_dot_f32_omp(int64_t rows, const int32_t *row_ptr,
+                            const int32_t *col_idx, const float *val,
+                            const float *x, float alpha, float *result, int threads) {
+  int used = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+    /* dynamic chunks: power-law rows make equal row counts unequal work */
+#pragma omp for schedule(dynamic, 2048)
+    for (int64_t i = 0; i < rows; i++) {
+      float acc = 0.0f;
+      for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+        acc += alpha * (x[col_idx[j]] * val[j]);
+      result[i] = acc;
+    }
+  }
+#else
+  (void)threads;
+  oracle_gold_dot_f32(rows, row_ptr, col_idx, val, x, alpha, result);
+#endif
+  return used;
 }
 
 /* ------------------------------------------------------------------------

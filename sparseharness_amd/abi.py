@@ -22,6 +22,13 @@ class sh_launch(C.Structure):
     _fields_ = [("global_", C.c_uint64 * 3), ("local", C.c_uint64 * 3)]
 
 
+class sh_plan_options(C.Structure):
+    """Plan options of sh_csr_upload_ex (field comments: include/sparseharness_hip.h)."""
+    _fields_ = [("plan", C.c_int32), ("autotune", C.c_int32), ("value_coding", C.c_int32), ("build_threads", C.c_int32),
+                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fused", C.c_int32),
+                ("ring", C.c_int32), ("n2", C.c_int32), ("slab_mb", C.c_double)]
+
+
 _vp, _i32, _i64, _u64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
 _pp = C.POINTER(C.c_void_p)
 
@@ -38,6 +45,9 @@ SIGNATURES = {
     "sh_engine_synchronize": (_int, [_vp]),
     "sh_last_error": (C.c_char_p, [_vp]),
     "sh_csr_upload": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),
+    "sh_plan_options_default": (None, [C.POINTER(sh_plan_options)]),
+    "sh_plan_options_from_env": (None, [C.POINTER(sh_plan_options)]),
+    "sh_csr_upload_ex": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(sh_plan_options), _pp]),
     "sh_csr_free": (_int, [_vp, _vp]),
     "sh_csr_dims": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sh_csr_algorithmic_bytes": (_int, [_vp, _int, C.POINTER(_u64)]),

@@ -112,10 +112,10 @@ static int fail(sh_engine *e, int code, const char *fmt, ...) {
                   __FILE__, __LINE__);                                          \
   } while (0)
 
-// Host threads for the plan build: SH_BUILD_THREADS, else the hardware's, at most 16.
-static int build_threads() {
+// Host threads for the plan build: the option, else the hardware's, at most 16.
+static int build_threads(const sh_plan_options &opt) {
   int n = (int)std::thread::hardware_concurrency();
-  if (const char *e = getenv("SH_BUILD_THREADS")) n = atoi(e);
+  if (opt.build_threads > 0) n = opt.build_threads;
   return std::max(1, std::min(n, 16));
 }
 // fn(item, thread) for every item in [0, n): items are handed out `grain` at a time from an atomic
@@ -277,12 +277,9 @@ int sh_engine_synchronize(sh_engine *e) {
 // (<= NNZ_BLK entries counted from the 16-byte-aligned start, <= ROWS_BLK
 // rows); rows that do not fit alone become long rows cut into SEG_NNZ pieces.
 static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t> &blk_row,
-                           std::vector<int32_t> &blk_flags, std::vector<LongSeg> &segs,
-                           std::vector<LongRow> &longs) {
-  // blk_row holds the row boundaries of stream blocks only; long rows are
-  // excluded by closing the current block before them (a stream block never
-  // spans a long row), so a parallel list of (r0, r1) pairs is kept instead.
-  (void)blk_flags;
+                           std::vector<LongSeg> &segs, std::vector<LongRow> &longs) {
+  // blk_row holds (first row, one-past-last row) pairs of stream blocks only; long rows are
+  // excluded by closing the current block before them (a stream block never spans a long row).
   int64_t r = 0;
   while (r < rows) {
     const int64_t s = rp[r];
@@ -349,12 +346,11 @@ struct TiledHost {
 };
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
-                             const int32_t *ci, const uint32_t *val, int n_cus, TiledHost &H) {
+                             const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
-  int64_t per_tile = 8;
-  if (const char *e = getenv("SH_HEAVY_PER_TILE")) per_tile = std::max(1, atoi(e));   // tuning knob
+  const int64_t per_tile = std::max(1, opt.heavy_per_tile);
   // (capped at TBIN/4 so that a single light row fits a bin even when every entry is padded to 4)
   const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
@@ -414,7 +410,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     const int64_t g0 = rel_start / 4, g1 = (rel_start + padded) / 4 - 1;
     return (int32_t)(g1 / 64 - g0 / 64 + 1);
   };
-  const int NT = build_threads();
+  const int NT = build_threads(opt);
   struct Scratch { std::vector<int32_t> count, touched; std::vector<int64_t> pos; };
   std::vector<Scratch> scratch((size_t)NT);
   for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
@@ -458,11 +454,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   {
     // default: one slab, P linear (two launches).  SH_SLAB_MB / SH_RING cut slabs and reuse P slots: that is
     // what the fused launch (SH_FUSED=1) is built around.
-    double cap_mb = 1e9;
-    if (const char *e = getenv("SH_SLAB_MB")) cap_mb = atof(e);
+    const double cap_mb = opt.slab_mb > 0 ? opt.slab_mb : 1e9;
     H.slab_cap = std::max<int64_t>(TBIN, (int64_t)std::min(cap_mb * 262144.0, 2e9)) & ~int64_t(3);
-    H.ring = 3;
-    if (const char *e = getenv("SH_RING")) H.ring = std::max(1, atoi(e));
+    H.ring = std::max(1, opt.ring);
     int64_t acc = 0;
     H.slab_bin0.push_back(0);
     for (int64_t bi = 0; bi < n_bins; bi++) {
@@ -544,8 +538,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // SH_VALCODE=off keeps raw values, SH_VALCODE=8 never packs nibbles.
   ValSet dict;
   {
-    const char *vc = getenv("SH_VALCODE");
-    bool coded = !(vc && !strcmp(vc, "off"));
+    bool coded = opt.value_coding >= 0;
+    const bool bytes_only = opt.value_coding == 8;
     if (coded) {
       std::vector<ValSet> part((size_t)NT);
       parallel_items((nnz + 65535) / 65536, 4, NT, [&](int64_t blk, int th) {
@@ -568,11 +562,11 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       dict = ValSet();
       if (all.overflow || words.size() > (size_t)VDICT) {
         dict.overflow = true;
-      } else if (!(vc && !strcmp(vc, "8")) && words.size() + (has_zero ? 0 : 1) <= 16) {
+      } else if (!bytes_only && words.size() + (has_zero ? 0 : 1) <= 16) {
         H.code_bits = 4;
         dict.add(0u);                      // code 0 = the all-zero word: padding
         for (uint32_t b : words) dict.add(b);
-      } else if (!(vc && !strcmp(vc, "8")) && words.size() == 16 && all_finite) {
+      } else if (!bytes_only && words.size() == 16 && all_finite) {
         H.code_bits = 4;                   // 16 finite values and no zero among them: padding borrows code 0's value
         for (uint32_t b : words) dict.add(b);
       } else if (words.size() + (has_zero ? 0 : 1) <= (size_t)VDICT) {
@@ -663,9 +657,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
   //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
   //    of all of it (speed only; correctness does not depend on placement).
-  int64_t chunk = TCHUNK;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
-  if (const char *e = getenv("SH_CHUNK")) chunk = std::max(1024, atoi(e)) & ~255;   // tuning knob
-  const bool xcd_order = !(getenv("SH_XCD_ORDER") && getenv("SH_XCD_ORDER")[0] == '0');
+  const int64_t chunk = std::max(1024, opt.chunk) & ~255;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
+  const bool xcd_order = opt.xcd_order != 0;
   std::vector<TileChunk> queue[8];
   H.need.assign((size_t)n_slabs * 2, 0);
   // cut one run into chunks
@@ -792,16 +785,53 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
   m->tuned_ms[1] = ms[PLAN_TILED];
 }
 
-static int choose_plan(int64_t cols, int64_t nnz) {
-  const char *e = getenv("SH_PLAN");
-  if (e && !strcmp(e, "stream")) return PLAN_STREAM;
-  if (e && !strcmp(e, "tiled")) return PLAN_TILED;
+static int choose_plan(const sh_plan_options &opt, int64_t cols, int64_t nnz) {
+  if (opt.plan == 1) return PLAN_STREAM;
+  if (opt.plan == 2) return PLAN_TILED;
   // auto: x beyond the per-XCD L2 (4 MiB) makes global gathers line-miss bound
   return (cols > (1 << 20) && nnz >= (1 << 22)) ? PLAN_TILED : PLAN_STREAM;
 }
 
+void sh_plan_options_default(sh_plan_options *o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->autotune = 1;
+  o->heavy_per_tile = 8;
+  o->chunk = TCHUNK;
+  o->xcd_order = 1;
+  o->ring = 3;
+  o->n2 = 16;
+  o->slab_mb = 0;   // one slab
+}
+
+void sh_plan_options_from_env(sh_plan_options *o) {
+  if (!o) return;
+  sh_plan_options_default(o);
+  auto num = [](const char *name, int32_t &dst) { if (const char *v = getenv(name)) dst = atoi(v); };
+  if (const char *v = getenv("SH_PLAN")) o->plan = !strcmp(v, "stream") ? 1 : (!strcmp(v, "tiled") ? 2 : 0);
+  if (const char *v = getenv("SH_AUTOTUNE")) o->autotune = v[0] != '0';
+  if (const char *v = getenv("SH_VALCODE")) o->value_coding = !strcmp(v, "off") ? -1 : (!strcmp(v, "8") ? 8 : 0);
+  num("SH_BUILD_THREADS", o->build_threads);
+  num("SH_HEAVY_PER_TILE", o->heavy_per_tile);
+  num("SH_CHUNK", o->chunk);
+  if (const char *v = getenv("SH_XCD_ORDER")) o->xcd_order = v[0] != '0';
+  if (const char *v = getenv("SH_FUSED")) o->fused = v[0] == '1';
+  num("SH_RING", o->ring);
+  num("SH_N2", o->n2);
+  if (const char *v = getenv("SH_SLAB_MB")) o->slab_mb = atof(v);
+}
+
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
                   const int32_t *col_idx, const void *val, sh_csr **out) {
+  sh_plan_options opt;
+  sh_plan_options_from_env(&opt);   // the SH_* knobs: read once per upload, never at launch time
+  return sh_csr_upload_ex(e, rows, cols, nnz, row_ptr, col_idx, val, &opt, out);
+}
+
+int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
+                     const int32_t *col_idx, const void *val, const sh_plan_options *opt_p, sh_csr **out) {
+  sh_plan_options opt;
+  if (opt_p) opt = *opt_p; else sh_plan_options_default(&opt);
   if (!e || !out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_idx || !val)))
     return fail(e, SH_EINVAL, "sh_csr_upload: bad argument");
   if (rows > INT32_MAX - 1 || cols > INT32_MAX || nnz > INT32_MAX - 8)
@@ -816,7 +846,7 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
     return fail(e, SH_ENOMEM, "out of host memory");
   m->rows = rows; m->cols = cols; m->nnz = nnz;
 
-  std::vector<int32_t> pairs, unused;
+  std::vector<int32_t> pairs;
   std::vector<LongSeg> segs;
   std::vector<LongRow> longs;
   for (int64_t r = 0; r < rows; r++)
@@ -824,7 +854,7 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
       delete m;
       return fail(e, SH_ESHAPE, "sh_csr_upload: row_ptr not monotone at row %lld", (long long)r);
     }
-  build_schedule(rows, row_ptr, pairs, unused, segs, longs);
+  build_schedule(rows, row_ptr, pairs, segs, longs);
   // compact (r0,r1) pairs into a boundary list usable as blk_row[b], blk_row[b+1]:
   // blocks are consecutive except across long rows, so store both ends.
   m->n_stream = (int32_t)(pairs.size() / 2);
@@ -864,8 +894,8 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
   }
   TiledHost th;
   m->plan = PLAN_STREAM;
-  if (choose_plan(cols, nnz) == PLAN_TILED && nnz > 0 &&
-      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, e->n_cus, th)) {
+  if (choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
+      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, th)) {
     m->plan = PLAN_TILED;
     m->n_bins = (int32_t)th.bins.size();
     m->n_chunks = (int32_t)th.chunks.size();
@@ -911,11 +941,8 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
       // Opt-in (SH_FUSED=1): measured slower than two launches on MI355X -- both roles are bound by what one CU
       // keeps in flight, not by HBM, so running them side by side on half the CUs each gains nothing
       // ("slab-pipelined fused launch"; profiles/r02_fused_*).
-      const char *fz = getenv("SH_FUSED");
-      m->fused = fz && fz[0] == '1' && e->n_cus >= 16;
-      m->n2 = 16;
-      if (const char *v = getenv("SH_N2")) m->n2 = atoi(v);
-      m->n2 = std::max(1, std::min(m->n2, e->n_cus / 8 - 1));
+      m->fused = opt.fused == 1 && e->n_cus >= 16;
+      m->n2 = std::max(1, std::min(opt.n2, e->n_cus / 8 - 1));
       // A phase-2 worker waits for its NEXT bin's slab while its current bin is unfinished.  That is only
       // free of cycles if the next bin (8 * n2 bins further) is at most one slab ahead and the slab after
       // the current one does not need the current one's ring slot: every slab but the last must hold
@@ -946,12 +973,9 @@ int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const i
   HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
 #undef HIP_TRY_M
   {
-    const char *forced = getenv("SH_PLAN");
-    const char *tune = getenv("SH_AUTOTUNE");
     // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
     // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
-    if (m->plan == PLAN_TILED && !(forced && (!strcmp(forced, "stream") || !strcmp(forced, "tiled"))) &&
-        !(tune && tune[0] == '0') && th.tile_fill < 0.5)
+    if (m->plan == PLAN_TILED && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5)
       autotune_plan(e, m);
   }
   *out = m;
@@ -1291,7 +1315,7 @@ extern "C" {
 int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
             const void *alpha, const void *beta, sh_vec *out, const sh_launch *launch,
             uint64_t *kernel_ns) {
-  (void)launch; // geometry comes from the matrix schedule (see header)
+  (void)launch;   // grid and workgroup size come from the matrix schedule (see header)
   int rc = check_operands(e, A, x, alpha, beta, out, "sh_spmv");
   if (rc)
     return rc;
@@ -1338,6 +1362,8 @@ int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const s
     return fail(e, SH_ESHAPE, "sh_iterate: matrix must be square (inc/common.h:49-52)");
   if (x->n < A->rows || scratch->n < A->rows || y0->n < A->rows)
     return fail(e, SH_ESHAPE, "sh_iterate: vectors shorter than the matrix");
+  if (scratch->d == x->d && A->rows > 0)
+    return fail(e, SH_EINVAL, "sh_iterate: scratch must not alias x");
   HIP_TRY(e, hipSetDevice(e->device));
   if (e->n_flags < 1) {
     HIP_TRY(e, hipMalloc((void **)&e->d_flags, 64));

@@ -755,6 +755,8 @@ constexpr int P2S_Q = P2S_K * P2S_LD;          // groups per step: 1024 (a quart
 constexpr int P2S_NS = TBIN / 4 / P2S_Q;       // steps per bin: 4
 constexpr int P2S_RPU = (TBIN_ROWS + P2S_RD) / P2S_RD;   // row_ptr entries per reducer thread: 3
 static_assert(P2S_NS * P2S_Q * 4 == TBIN && P2S_NS % 2 == 0 && TBIN_ROWS + 1 <= P2S_RPU * P2S_RD, "phase-2 geometry");
+// a light row is shorter than TBIN / 4: never the workgroup-wide reduction path, whose extra barriers only the reducers would execute
+static_assert(TBIN / 4 <= RL_WAVE, "light rows must not reach the workgroup-wide reduction of reduce_rows_from_lds");
 
 // LDS of the phase-2 role
 struct P2Lds {

@@ -139,15 +139,25 @@ class Engine:
         self._chk(abi.load().sh_engine_synchronize(self.h))
 
     # ---- buffers
-    def upload_csr(self, rows, cols, row_ptr, col_idx, val):
+    def upload_csr(self, rows, cols, row_ptr, col_idx, val, **options):
+        """options: fields of sh_plan_options (plan=0|1|2, value_coding=0|8|-1, fused=1, ...) on top of the
+        SH_* environment; without any the environment alone decides (sh_csr_upload)."""
         row_ptr = np.ascontiguousarray(row_ptr, np.int32)
         col_idx = np.ascontiguousarray(col_idx, np.int32)
         val = np.ascontiguousarray(val)
         assert val.dtype.itemsize == 4
         nnz = int(row_ptr[-1]) if len(row_ptr) else 0
         h = C.c_void_p()
-        self._chk(abi.load().sh_csr_upload(self.h, rows, cols, nnz, _ptr(row_ptr), _ptr(col_idx),
-                                           _ptr(val), C.byref(h)))
+        lib = abi.load()
+        if options:
+            opt = abi.sh_plan_options()
+            lib.sh_plan_options_from_env(C.byref(opt))
+            for k, v in options.items():
+                setattr(opt, k, v)
+            self._chk(lib.sh_csr_upload_ex(self.h, rows, cols, nnz, _ptr(row_ptr), _ptr(col_idx), _ptr(val),
+                                           C.byref(opt), C.byref(h)))
+        else:
+            self._chk(lib.sh_csr_upload(self.h, rows, cols, nnz, _ptr(row_ptr), _ptr(col_idx), _ptr(val), C.byref(h)))
         return CsrMatrix(self, h, rows, cols, nnz)
 
     def alloc(self, n):

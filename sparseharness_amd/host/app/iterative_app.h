@@ -54,20 +54,23 @@ public:
         run_runtimes.push_back(SqlStat(total_time, NOT_CHECKED, run.global1, run.local1, MULTI_ITERATION_SUM));
         runtimes.push_back(run_runtimes);
       }
-      if (t + 1 < this->_trials)
-        this->resetInputs();
+      // the final vector of this trial is kept on the host, then -- after EVERY trial, as the reference does
+      // (app/sssp.cpp:88-90) -- the inputs go back to their initial state: the next trial and the next run of
+      // a multi-line run-file start from x0 / y0 again
+      {
+        std::vector<char> bytes(this->_args.x_vect.size());
+        this->readFromGlobalArg(bytes, _final_mem);
+        _final_host = dechar<SemiRingType>(bytes);
+      }
+      this->resetInputs();
     }
     return runtimes;
   }
 
   int lastIterations() const { return _last_iters; }
   bool lastConverged() const { return _last_converged; }
-  // final vector of the last trial (host copy)
-  std::vector<SemiRingType> finalVector() {
-    std::vector<char> bytes(this->_args.x_vect.size());
-    this->readFromGlobalArg(bytes, _final_mem);
-    return dechar<SemiRingType>(bytes);
-  }
+  // final vector of the last trial (host copy taken before the inputs were reset)
+  std::vector<SemiRingType> finalVector() { return _final_host; }
 
 protected:
   std::vector<SqlStat> executeRun(Run run, unsigned int trial, std::vector<SemiRingType> &) override {
@@ -120,6 +123,7 @@ private:
   int _last_iters = 0;
   bool _last_converged = false;
   device_mem _final_mem = nullptr;
+  std::vector<SemiRingType> _final_host;
 };
 
 inline bool env_host_loop() {

@@ -14,9 +14,9 @@ HOST = os.path.join(ROOT, "sparseharness_amd", "host")
 KERNELS = os.path.join(HOST, "kernels")
 
 
-def run_app(app, matrix, kernel, env_extra=None, *extra):
+def run_app(app, matrix, kernel, env_extra=None, *extra, runfile=None):
     cmd = [os.path.join(HOST, "bin", app), "-m", mtx(matrix), "-f", matrix, "-k", os.path.join(KERNELS, kernel),
-           "-r", os.path.join(KERNELS, "runfile.csv"), "-n", "gpubox", "-e", "exp7", "-i", "3", *extra]
+           "-r", runfile or os.path.join(KERNELS, "runfile.csv"), "-n", "gpubox", "-e", "exp7", "-i", "3", *extra]
     env = {k: v for k, v in os.environ.items() if k != "SH_QUIET_TIMERS"}
     env.update(env_extra or {})
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
@@ -131,7 +131,10 @@ def test_bench_script_emits_the_contract_line():
     assert "workload" in d["config"] and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
+    ac = d["cpu_baseline"]["all_cores"]
+    assert ac["cores"] >= 1 and ac["value"] > 0 and ac["same_bits_as_single_thread"]
     assert d["parity"]["mismatches_rel_1e-5"] == 0 and d["value"] > 0
+    assert d["frac_raw_values"] is None or 0 < d["frac_raw_values"] < 1
 
 
 def test_bench_script_two_ranks_rehearsal():
@@ -155,3 +158,23 @@ def test_bench_script_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["nnz"] == 8000000
     assert 0 < d["roofline"]["rank_nnz"] < 8000000 and d["parity"]["mismatches_rel_1e-5"] == 0
     assert d["cpu_baseline"] is None and "rehearsal" in d
+
+
+def test_bench_script_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher around it, WORLD_SIZE unset): the parent spawns the ranks
+    before it touches torch / HIP, relays rank 0's JSON line and exits with the children's return code."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SH_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--nnz", "8000000",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-1200:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity"]["mismatches_rel_1e-5"] == 0 and "rehearsal" in d
+    # and a failing rank fails the parent
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--nnz", "8000000"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, SH_LIB="/nonexistent/engine.so"))
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

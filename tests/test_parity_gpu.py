@@ -618,3 +618,60 @@ def test_config4_rmat23_sssp_and_bfs_to_convergence(eng, plan):
         for v in (xv, yv, sc):
             v.free()
         A.free()
+
+
+def test_config3_rmat23_float_spmv_full_size(eng, plan):
+    """BASELINE.json config 3 at full size: float (+,x) SpMV on R-MAT scale 23 (134 M entries, x = 1 + (i mod 7),
+    integer weights 1..16).  Every row whose |terms| sum stays below 2^24 is order-independent in float and must
+    equal the sequential gold bit for bit (inc/harness.h:134, exact compare); the few hub rows beyond that are
+    named and held to 1e-5 of the exact (float64) dot."""
+    import os
+    if plan != "tiled" or os.environ.get("SH_VALCODE") != "auto":
+        pytest.skip("full size once, under the layout the engine picks for it")
+    rp, ci, va = H.rmat(23)
+    n = 1 << 23
+    x = (1 + np.arange(n) % 7).astype(np.float32)
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert A.plan()[0] == "tiled", A.describe()
+    xv, out = eng.vector(x), eng.alloc(n).fill(0)
+    ns = eng.spmv(O.PLUS_TIMES_F32, A, xv, None, 1.0, 0.0, out, timed=True)
+    got = out.download(np.float32)
+    want = O.gold_dot(rp, ci, va, x, 1.0)
+    assert ns > 0 and O.check_result(want, got) in (O.CORRECT, O.BAD_VALUES)
+    # an upper bound of a row's |terms| sum: 16 * 7 * length
+    big = np.nonzero(np.diff(rp).astype(np.int64) * 112 >= 2 ** 24)[0]
+    small = np.ones(n, bool)
+    small[big] = False
+    np.testing.assert_array_equal(bits(got[small]), bits(want[small]))
+    for r in big:   # hub rows: the sequential float gold itself is inexact there
+        a, b = int(rp[r]), int(rp[r + 1])
+        exact = float((x[ci[a:b]].astype(np.float64) * va[a:b].astype(np.float64)).sum())
+        assert abs(float(got[r]) - exact) <= REL * max(1.0, abs(exact)), (r, got[r], exact)
+    assert len(big) < 64
+    for v in (xv, out):
+        v.free()
+    A.free()
+
+
+def test_config2_scircuit_shaped_float_spmv(eng, plan, monkeypatch):
+    """BASELINE.json config 2 (stand-in of SuiteSparse scircuit's shape: 170 998 rows, 958 936 entries; the file
+    itself is not available offline): x fits the per-XCD L2, so the engine picks the CSR-stream plan BY ITSELF
+    (no SH_PLAN), and the result equals the gold bit for bit (integer weights, sums far below 2^24)."""
+    if plan != "stream":
+        pytest.skip("once; the plan is chosen by the engine here")
+    monkeypatch.delenv("SH_PLAN", raising=False)
+    rp, ci, va = H.scircuit_like()
+    n = len(rp) - 1
+    assert (n, int(rp[-1])) == (170_998, 958_936)
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert A.plan()[0] == "stream" and "tuned" not in A.describe(), A.describe()
+    for x in (np.ones(n, np.float32), (1 + np.arange(n) % 7).astype(np.float32)):
+        xv, out = eng.vector(x), eng.alloc(n).fill(0)
+        eng.spmv(O.PLUS_TIMES_F32, A, xv, None, 1.0, 0.0, out)
+        got = out.download(np.float32)
+        want = O.gold_dot(rp, ci, va, x, 1.0)
+        np.testing.assert_array_equal(bits(got), bits(want))
+        assert O.check_result(want, got) == O.CORRECT
+        for v in (xv, out):
+            v.free()
+    A.free()

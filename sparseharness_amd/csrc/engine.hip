@@ -28,6 +28,7 @@ struct sh_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_iter[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // sh_iterate: one per launch of a batch
   int32_t *d_flags = nullptr;   // per-iteration convergence flags
   int32_t n_flags = 0;
   int32_t *h_flag = nullptr;    // pinned, 64 B: [0] convergence flag read-back, [8] give-up word of the fused launch
@@ -243,6 +244,7 @@ int sh_engine_destroy(sh_engine *e) {
   if (e->h_flag) (void)hipHostFree(e->h_flag);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (auto ev : e->ev_iter) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return SH_OK;
@@ -1172,15 +1174,15 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       if (A->n_vdict && A->code_bits == 4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
                            ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
       else if (A->n_vdict)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
                            ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
                            ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial);
+                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
     };
     const int n_slabs = (int)A->slab_bin0.size() - 1;
     if (A->fused) {
@@ -1369,34 +1371,55 @@ int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const s
     HIP_TRY(e, hipMalloc((void **)&e->d_flags, 64));
     e->n_flags = 16;
   }
+  // Launches are enqueued ITER_BATCH iterations ahead of the host: iteration i carries the flag word of
+  // iteration i - 1 as its gate and returns at once when that flag stayed 0 (nothing changed: the loop is
+  // over), so the host only joins in once per batch -- one memset, one 32-byte read-back, one synchronise
+  // per 8 iterations instead of per iteration.  The launch count of the reference's do/while
+  // (app/sssp.cpp:112-153, confirming launch included) = index of the first flag that stayed 0, plus one.
+#ifndef SH_ITER_BATCH
+#define SH_ITER_BATCH 8
+#endif
+  constexpr int ITER_BATCH = SH_ITER_BATCH;   // (1 = one host round trip per iteration, the round-1 loop: tools A/B builds)
+  static_assert(ITER_BATCH <= 8, "the flags of a batch are read back into the first 8 words of h_flag");
+  if (!e->ev_iter[0])
+    for (auto &ev : e->ev_iter) HIP_TRY(e, hipEventCreate(&ev));
   sh_vec *in = x, *out = scratch;
   const sh_vec *y = y0;
   int32_t it = 0;
   bool term = false;
   uint64_t total = 0;
-  do {
-    HIP_TRY(e, hipMemsetAsync(e->d_flags, 0, 4, e->stream));
-    StepDev st{e->d_flags, (const uint32_t *)in->d, 0, delta};
-    HIP_TRY(e, hipEventRecord(e->ev0, e->stream));
-    int rc = dispatch(e, sr, A, in, y, alpha, beta, out, st);
-    if (rc)
-      return rc;
-    HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(e->h_flag, e->d_flags, 4, hipMemcpyDeviceToHost, e->stream));
+  while (!term && it < max_iters) {
+    const int nb = std::min<int32_t>(ITER_BATCH, max_iters - it);
+    HIP_TRY(e, hipMemsetAsync(e->d_flags, 0, ITER_BATCH * 4, e->stream));
+    HIP_TRY(e, hipEventRecord(e->ev_iter[0], e->stream));
+    for (int k = 0; k < nb; k++) {
+      StepDev st{e->d_flags + k, (const uint32_t *)in->d, 0, delta, k > 0 ? e->d_flags + (k - 1) : nullptr};
+      int rc = dispatch(e, sr, A, in, y, alpha, beta, out, st);
+      if (rc)
+        return rc;
+      HIP_TRY(e, hipEventRecord(e->ev_iter[k + 1], e->stream));
+      sh_vec *t = in; in = out; out = t;   // std::swap(input, output), app/sssp.cpp:143
+      y = in;                              // setGlobalArg(3, input_mem_ptr), :150
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->h_flag, e->d_flags, ITER_BATCH * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (int gu = check_gave_up(e)) return gu;
-    float ms = 0.f;
-    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    const uint64_t ns = (uint64_t)((double)ms * 1e6);
-    if (ns_per_iter)
-      ns_per_iter[it] = ns;
-    total += ns;
-    term = (*e->h_flag == 0);
-    sh_vec *t = in; in = out; out = t;   // std::swap(input, output), app/sssp.cpp:143
-    y = in;                              // setGlobalArg(3, input_mem_ptr), :150
-    it++;
-  } while (!term && it < max_iters);
-  if (in != x) {
+    int ran = nb;                          // launches of this batch that did run
+    for (int k = 0; k < nb; k++)
+      if (e->h_flag[k] == 0) { ran = k + 1; term = true; break; }
+    for (int k = 0; k < ran; k++) {
+      float ms = 0.f;
+      HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_iter[k], e->ev_iter[k + 1]));
+      const uint64_t ns = (uint64_t)((double)ms * 1e6);
+      if (ns_per_iter)
+        ns_per_iter[it + k] = ns;
+      total += ns;
+    }
+    // the gated launches behind the confirming one wrote nothing: the result is what launch `ran` produced
+    if ((nb - ran) % 2) { sh_vec *t = in; in = out; out = t; }
+    it += ran;
+  }
+  if (in != x) {   // the final vector lives in `scratch`: hand it back in x
     HIP_TRY(e, hipMemcpyAsync(x->d, in->d, A->rows * 4, hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }

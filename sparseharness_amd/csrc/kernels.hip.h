@@ -50,7 +50,11 @@ struct StepDev {
   const uint32_t *prev;     // previous vector; row r compares prev[prev_off + r]
   int64_t prev_off;
   double delta;
+  // Launches of an iteration loop are enqueued several iterations ahead of the host (sh_iterate): a launch
+  // whose gate word is 0 -- the previous iteration changed nothing, the loop is over -- returns at once.
+  const int32_t *gate = nullptr;
 };
+__device__ __forceinline__ bool gate_closed(const StepDev &st) { return st.gate != nullptr && *st.gate == 0; }
 
 struct LongSeg { int32_t row, s, e, slot; };
 struct LongRow { int32_t row, slot0, nslots, pad; };
@@ -216,6 +220,8 @@ __global__ __launch_bounds__(BS) void spmv_csr_kernel(
     const int32_t *__restrict__ blk_row, int32_t n_stream,
     const LongSeg *__restrict__ segs, uint32_t *__restrict__ partial, StepDev st) {
   using T = typename SR::T;
+  if (gate_closed(st))
+    return;
   __shared__ uint32_t prod[NNZ_BLK];
   __shared__ int32_t rp[ROWS_BLK + 1];
   __shared__ ReduceScratch<BS, NNZ_BLK> sc;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(64) void spmv_long_fixup(
     uint32_t *__restrict__ out, StepDev st) {
   using T = typename SR::T;
   const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n_long)
+  if (i >= n_long || gate_closed(st))
     return;
   const LongRow lr = rows[i];
   T acc = SR::identity();
@@ -338,6 +344,8 @@ __global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
     const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta, int use_y_i,
     uint32_t *__restrict__ out, StepDev st) {
   using T = typename SR::T;
+  if (gate_closed(st))
+    return;
   __shared__ uint32_t wred[HFIX_BS / 64];
   const LongRow lr = rows[blockIdx.x];
   const int tid = threadIdx.x;
@@ -697,12 +705,12 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial) {
+    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial, const int32_t *gate) {
   __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC ? VDICT : 1];
   const TileChunk ch = chunks[blockIdx.x];
-  if (ch.s >= ch.e)
-    return;   // filler that keeps the XCD-aligned chunk order
+  if (ch.s >= ch.e || (gate != nullptr && *gate == 0))
+    return;   // filler that keeps the XCD-aligned chunk order / the iteration loop is over (StepDev::gate)
 #ifdef SH_FORCE_WT   // tuning builds: write-through stores in the separate launches too
   tiled_phase1_chunk<SR, VC, true>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
 #else
@@ -1033,6 +1041,8 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
     const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
     typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   __shared__ P2Lds L;
+  if (gate_closed(st))
+    return;
   const int G = gridDim.x;
   // consecutive bins on one XCD: workgroups are dealt round-robin over the 8 XCDs (blocks w and
   // w+8 share one) and neighbouring bins own neighbouring pieces of every tile in P, so the 128-B
@@ -1101,6 +1111,8 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_fused(
     const FusedDev D, const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
     int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   static_assert(P2S_BS == TBS, "both roles use the whole workgroup");
+  if (gate_closed(st))
+    return;
   __shared__ union { P2Lds p2; uint32_t xs[TCOLS + 4]; } U;
   __shared__ uint32_t ds[VC ? VDICT : 1];
   __shared__ int32_t claim;

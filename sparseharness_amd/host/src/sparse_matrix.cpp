@@ -258,7 +258,66 @@ template <typename T> void SparseMatrix<T>::store_to_cache(const std::string &fi
     std::remove(tmp.c_str());
 }
 
+// "synth:powerlaw:<rows>:<nnz>", "synth:rmat:<scale>", "synth:rmat-unpermuted:<scale>", "synth:scircuit" in place
+// of a file name: the seeded generators of SURVEY.md 8d (synth.cpp), so that BASELINE.json's synthetic configs
+// run through the same apps -- Harness<>::benchmark -> executeKernel -- as a MatrixMarket file does.
+template <typename T> static bool synthetic_spec(const std::string &spec, int &rows, int &cols, std::vector<int32_t> &rp,
+                                                 std::vector<int32_t> &ci, std::vector<T> &va) {
+  if (spec.compare(0, 6, "synth:") != 0)
+    return false;
+  std::vector<std::string> part;
+  for (std::size_t a = 6; a <= spec.size();) {
+    const std::size_t b = std::min(spec.find(':', a), spec.size());
+    part.push_back(spec.substr(a, b - a));
+    a = b + 1;
+  }
+  int64_t n = 0, nnz = 0;
+  int rc = -1;
+  std::vector<float> fv;
+  auto alloc = [&]() { rp.assign((std::size_t)n + 1, 0); ci.assign((std::size_t)nnz, 0); fv.assign((std::size_t)nnz, 0.f); };
+  if (part.size() == 3 && part[0] == "powerlaw") {
+    n = std::atoll(part[1].c_str()); nnz = std::atoll(part[2].c_str());
+    if (n > 0 && nnz > 0 && n < INT32_MAX && nnz < INT32_MAX) {
+      alloc();
+      rc = sh_synth_powerlaw(n, n, nnz, 2.1, std::min<int64_t>(1000000, n), 0x5EED1000ull, rp.data(), ci.data(), fv.data());
+    }
+  } else if (part.size() == 2 && (part[0] == "rmat" || part[0] == "rmat-unpermuted")) {
+    const int scale = std::atoi(part[1].c_str());
+    if (scale > 0 && scale < 27) {
+      n = (int64_t)1 << scale; nnz = 16 * n;
+      alloc();
+      rc = sh_synth_rmat(scale, 16, 0.57, 0.19, 0.19, 0x5EED0023ull, part[0] == "rmat", rp.data(), ci.data(), fv.data());
+    }
+  } else if (part.size() == 1 && part[0] == "scircuit") {
+    n = 170998; nnz = 958936;
+    alloc();
+    rc = sh_synth_powerlaw(n, n, nnz, 2.1, 353, 0x5EED5C1Cull, rp.data(), ci.data(), fv.data());
+  }
+  if (rc != 0) {
+    std::cerr << "Bad synthetic matrix spec " << spec << " (synth:powerlaw:<rows>:<nnz> | synth:rmat:<scale> | synth:scircuit)" << ENDL;
+    std::exit(-1);
+  }
+  rows = cols = (int)n;
+  va.resize(fv.size());
+  for (std::size_t k = 0; k < fv.size(); k++)
+    va[k] = (T)fv[k];
+  return true;
+}
+
 template <typename T> SparseMatrix<T>::SparseMatrix(std::string filename) {
+  if (synthetic_spec<T>(filename, rows, cols, row_ptr_, col_idx_, val_)) {
+    start_timer(synthetic_matrix, SparseMatrix);
+    nonz = (int)col_idx_.size();
+    for (int i = 0; i < rows; i++)
+      max_width = std::max<unsigned>(max_width, (unsigned)(row_ptr_[i + 1] - row_ptr_[i]));
+    if (keep_flag()) {   // (a generated matrix has no file: CSR order stands in for file order)
+      raw_val_ = val_;
+      file_order_.resize(col_idx_.size());
+      for (std::size_t k = 0; k < file_order_.size(); k++)
+        file_order_[k] = (int32_t)k;
+    }
+    return;
+  }
   if (load_from_cache(filename))
     return;
   load_from_file(filename);

@@ -6,12 +6,13 @@ ranges with ~equal non-zeros (power-law rows make equal-row cuts badly
 imbalanced); every rank keeps a full replica of x.
 
 For the iterative apps the result vector of one iteration is the next
-iteration's x, so ranks exchange their slices with ONE all-gather per
-iteration.  To make that a plain equal-size all-gather with no copies, vectors
-live in a *slotted layout*: rank k owns slot k of `slot` elements
-(slot = longest row range rounded up to 64, plus one 64-element tail whose first
-word carries the rank's "changed" flag), and column indices are remapped once,
-on the host, from global row ids to slotted positions.
+iteration's x, so ranks exchange their slices by all-gather every iteration.
+To make that a plain equal-size in-place all-gather with no copies, vectors
+live in the layout of SlottedLayout (equal-size pieces per rank, a 64-element
+tail carrying the rank's "changed" flag), optionally cut into chunks so that
+the all-gather of a finished chunk overlaps the computation of the next one;
+column indices are remapped once, on the host, from global row ids to layout
+positions.
 """
 import numpy as np
 
@@ -48,46 +49,90 @@ def take_rows(row_ptr, col_idx, val, r0, r1):
 
 
 class SlottedLayout:
-    """Mapping between global vector indices and the slotted all-gather layout."""
+    """Mapping between global vector indices and the all-gather layout.
 
-    FLAG_PAD = 64  # elements reserved at the end of each slot; word 0 = changed flag
+    Every rank's row range is cut into `chunks` pieces of `piece` rows (the longest range / chunks,
+    rounded up to 64), and the vector is laid out CHUNK-major: region c holds piece c of rank 0, of
+    rank 1, ... -- so the all-gather of one chunk is an ordinary in-place equal-size all-gather over a
+    contiguous region, and a rank can gather its finished chunk c while it still computes chunk c + 1.
+    The pieces of the LAST region carry a 64-element tail whose first word is the rank's "changed"
+    flag: it travels with the last chunk, after every chunk of the iteration has been computed.
+    chunks = 1 is the plain slotted layout (rank k owns slot k)."""
 
-    def __init__(self, bounds):
+    FLAG_PAD = 64  # elements reserved behind each piece of the last region; word 0 = changed flag
+
+    def __init__(self, bounds, chunks=1):
         self.bounds = np.asarray(bounds, dtype=np.int64)
         self.parts = len(self.bounds) - 1
+        self.chunks = max(1, int(chunks))
         longest = int(np.diff(self.bounds).max()) if self.parts else 0
-        self.payload = (longest + 63) // 64 * 64
-        self.slot = self.payload + self.FLAG_PAD
+        self.piece = (-(-longest // self.chunks) + 63) // 64 * 64     # rows per piece
+        self.payload = self.piece * self.chunks
+        self.slot = self.payload + self.FLAG_PAD                      # elements a rank owns in total
         self.length = self.slot * self.parts
 
+    # ---- geometry
+    def piece_len(self, c):
+        """Elements one rank contributes to region c."""
+        return self.piece + (self.FLAG_PAD if c == self.chunks - 1 else 0)
+
+    def region(self, c):
+        """(start, length) of region c = what one all-gather of chunk c covers."""
+        return c * self.parts * self.piece, self.parts * self.piece_len(c)
+
+    def piece_offset(self, k, c):
+        """Position of row 0 of rank k's piece c."""
+        return self.region(c)[0] + k * self.piece_len(c)
+
+    def piece_rows(self, k, c):
+        """(first local row, row count) of rank k's piece c (the count may be 0)."""
+        n = int(self.bounds[k + 1] - self.bounds[k])
+        lo = min(n, c * self.piece)
+        return lo, min(n, (c + 1) * self.piece) - lo
+
     def slot_offset(self, k):
-        return k * self.slot
+        """chunks == 1 only: where rank k's rows start."""
+        assert self.chunks == 1
+        return self.piece_offset(k, 0)
 
     def flag_index(self, k):
-        return k * self.slot + self.payload
+        return self.piece_offset(k, self.chunks - 1) + self.piece
+
+    def _pos(self, owner, local):
+        c = local // max(self.piece, 1)
+        c = np.minimum(c, self.chunks - 1)
+        plen = np.where(c == self.chunks - 1, self.piece + self.FLAG_PAD, self.piece)
+        return c * self.parts * self.piece + owner * plen + (local - c * self.piece)
 
     def to_slotted_index(self, idx):
-        """Global ids -> slotted positions (out-of-range ids stay out of range => identity)."""
+        """Global ids -> layout positions (out-of-range ids stay out of range => identity)."""
         idx = np.asarray(idx)
         owner = np.searchsorted(self.bounds, idx, side="right") - 1
         valid = (idx >= 0) & (idx < self.bounds[-1])
-        owner = np.clip(owner, 0, self.parts - 1)
-        pos = owner.astype(np.int64) * self.slot + (idx - self.bounds[owner])
+        owner = np.clip(owner, 0, self.parts - 1).astype(np.int64)
+        pos = self._pos(owner, idx.astype(np.int64) - self.bounds[owner])
         return np.where(valid, pos, -1).astype(np.int32)
 
     def scatter(self, global_vec, fill):
-        """Global vector -> slotted vector (padding = `fill`, flags = 0)."""
+        """Global vector -> layout vector (padding = `fill`, flags = 0)."""
         out = np.full(self.length, fill, dtype=global_vec.dtype)
         for k in range(self.parts):
-            r0, r1 = self.bounds[k], self.bounds[k + 1]
-            out[k * self.slot:k * self.slot + (r1 - r0)] = global_vec[r0:r1]
-            out[self.flag_index(k):(k + 1) * self.slot] = 0
+            for c in range(self.chunks):
+                lo, n = self.piece_rows(k, c)
+                o = self.piece_offset(k, c)
+                out[o:o + n] = global_vec[self.bounds[k] + lo:self.bounds[k] + lo + n]
+            f = self.flag_index(k)
+            out[f:f + self.FLAG_PAD] = 0
         return out
 
     def gather(self, slotted_vec):
-        """Slotted vector -> global vector."""
-        parts = [slotted_vec[k * self.slot:k * self.slot + (self.bounds[k + 1] - self.bounds[k])]
-                 for k in range(self.parts)]
+        """Layout vector -> global vector."""
+        parts = []
+        for k in range(self.parts):
+            for c in range(self.chunks):
+                lo, n = self.piece_rows(k, c)
+                o = self.piece_offset(k, c)
+                parts.append(slotted_vec[o:o + n])
         return np.concatenate(parts) if parts else slotted_vec[:0]
 
     def flags(self, slotted_vec):

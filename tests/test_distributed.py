@@ -27,21 +27,25 @@ class OracleLocalStep:
     def __init__(self, plan, semiring):
         self.plan, self.semiring = plan, semiring
 
-    def step(self, x_cur, y_slot, x_next, alpha, beta, delta):
+    def step(self, c, x_cur, y_piece, x_next, alpha, beta, delta):
         p, lay = self.plan, self.plan.layout
+        rp, ci, va, rows = p.pieces[c]
+        if rows == 0:
+            return
         dt = O.elem_dtype(self.semiring)
         x = x_cur.numpy().view(dt)
-        y = y_slot.numpy().view(dt)[:p.rows]
-        out = O.kernel(self.semiring, p.row_ptr, p.col_idx, p.val.astype(dt), x, y, alpha, beta, vlength=lay.length)
-        off = lay.slot_offset(p.rank)
-        prev = x[off:off + p.rows]
+        y = y_piece.numpy().view(dt)[:rows]
+        out = O.kernel(self.semiring, rp, ci, va.astype(dt), x, y, alpha, beta, vlength=lay.length)
+        off = lay.piece_offset(p.rank, c)
+        prev = x[off:off + rows]
         if self.semiring in (O.OR_AND_I32, O.MAX_MIN_I32):
             changed = bool((prev != out).any())
         else:
             changed = bool((~(np.abs(prev - out).astype(np.float64) < delta)).any())
         xn = x_next.numpy().view(dt)
-        xn[off:off + p.rows] = out
-        x_next.numpy().view(np.int32)[lay.flag_index(p.rank)] = int(changed)
+        xn[off:off + rows] = out
+        if changed:   # (the driver cleared the word before chunk 0; every chunk may raise it)
+            x_next.numpy().view(np.int32)[lay.flag_index(p.rank)] = 1
 
 
 def initial_y(sr, x0):
@@ -55,13 +59,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, q):
+def _worker(rank, world, port, case, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sr, rp, ci, va, a, b = case
         n = len(rp) - 1
-        plan = ShardPlan(rp, ci, va, rank, world)
+        plan = ShardPlan(rp, ci, va, rank, world, chunks)
         x0 = O.initial_vector(sr, n)
         final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, initial_y(sr, x0), a, b,
                                                                                        1e-4, 500)
@@ -70,11 +74,11 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-def run_world(world, case):
+def run_world(world, case, chunks=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -117,6 +121,20 @@ def test_sharded_iteration_matches_single_process(name, world):
         np.testing.assert_array_equal(want, golden("matrix5")["scc_final"])
 
 
+@pytest.mark.parametrize("name,world,chunks", [("rmat11_sssp", 2, 2), ("1138bus_bfs", 3, 3), ("rmat11_bfs", 2, 4), ("matrix5_scc", 2, 5)])
+def test_chunked_overlapped_all_gather_matches_single_process(name, world, chunks):
+    """chunks > 1: every rank's rows in pieces, the vector laid out chunk-major, one asynchronous in-place
+    all-gather per chunk issued while the next chunk is computed (the flags ride behind the last one).
+    Same vectors and launch counts as the single-process loop, bit for bit."""
+    case = cases()[name]
+    sr, rp, ci, va, a, b = case
+    x0 = O.initial_vector(sr, len(rp) - 1)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, initial_y(sr, x0), a, b, 1e-4, 500)
+    for rank, final, iters, conv in run_world(world, case, chunks):
+        assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
+        np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
+
+
 def test_world1_driver_equals_oracle():
     sr, rp, ci, va, a, b = cases()["rmat11_sssp"]
     n = len(rp) - 1
@@ -140,6 +158,25 @@ def test_row_bounds_balance_nnz():
     b = partition.row_bounds(np.array([0, 5], np.int32), 4)
     assert b.tolist()[0] == 0 and b.tolist()[-1] == 1
     assert partition.row_bounds(np.zeros(1, np.int32), 2).tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 5])
+def test_chunked_layout_roundtrip_and_remap(chunks):
+    bounds = np.array([0, 5, 5, 130, 200, 1000])
+    lay = partition.SlottedLayout(bounds, chunks)
+    assert sum(lay.region(c)[1] for c in range(chunks)) == lay.length and lay.piece % 64 == 0
+    v = np.arange(1000, dtype=np.float32)
+    s = lay.scatter(v, np.float32(-1))
+    np.testing.assert_array_equal(lay.gather(s), v)
+    idx = np.array([0, 4, 5, 129, 130, 199, 999, -1, 1000, 10**6])
+    pos = lay.to_slotted_index(idx)
+    assert pos[-3:].tolist() == [-1, -1, -1]
+    np.testing.assert_array_equal(s[pos[:7]], v[idx[:7]])
+    flags = [lay.flag_index(k) for k in range(5)]
+    start, length = lay.region(chunks - 1)
+    assert len(set(flags)) == 5 and all(start <= f < start + length for f in flags)   # the flags ride in the last region
+    for k in range(5):   # a rank's pieces tile its row range
+        assert sum(lay.piece_rows(k, c)[1] for c in range(chunks)) == bounds[k + 1] - bounds[k]
 
 
 def test_slotted_layout_roundtrip_and_remap():

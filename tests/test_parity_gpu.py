@@ -509,10 +509,12 @@ def test_full_size_powerlaw_properties(eng, rows, nnz, plan):
     np.testing.assert_array_equal(out3.download()[small], 3 * y1[small])
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
 @pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
-def test_sharded_driver_with_hip_local_step(cases, sr):
+def test_sharded_driver_with_hip_local_step(cases, sr, chunks):
     """The multi-GPU iteration driver's device seam (HipLocalStep -> sh_spmv_step on torch memory,
-    slotted vector layout, fused changed flag) on one rank; the N>1 logic is covered under gloo."""
+    slotted / chunked vector layout, one matrix per chunk, fused changed flag raised by any chunk) on one
+    rank; the N>1 logic is covered under gloo."""
     import torch
     from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
     rp, ci, va, n = cases["rmat15"]
@@ -522,7 +524,7 @@ def test_sharded_driver_with_hip_local_step(cases, sr):
     x0 = O.initial_vector(sr, n)
     want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 60)
     torch.cuda.set_device(0)
-    plan = ShardPlan(rp, ci, vals, 0, 1)
+    plan = ShardPlan(rp, ci, vals, 0, 1, chunks)
     final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0)).run(x0, x0, a, b, 1e-4, 60)
     assert (iters, conv) == (w_it, w_conv)
     np.testing.assert_array_equal(bits(final), bits(want))

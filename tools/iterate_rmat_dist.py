@@ -3,7 +3,7 @@
 over the ranks (nnz-balanced), ONE in-place RCCL all-gather of the new vector per iteration.
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      tools/iterate_rmat_dist.py [scale=23] [--check]
+      tools/iterate_rmat_dist.py [scale=23] [--check] [--chunks=C]
 
 Rank 0 prints one JSON line: iterations, wall time per iteration (max over ranks), and with --check the
 bit-exact comparison against the CPU oracle (slow: single thread)."""
@@ -24,6 +24,7 @@ from sparseharness_amd.engine import MIN_PLUS_F32, OR_AND_I32  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 scale = int(args[0]) if args else 23
 check = "--check" in sys.argv
+chunks = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--chunks=")), 1)
 rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
 torch.cuda.set_device(local)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -32,11 +33,11 @@ dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.dev
 
 rp, ci, va = H.rmat(scale)
 n = 1 << scale
-out = {"workload": f"rmat-{scale}", "rows": n, "nnz": int(rp[-1]), "n_gpus": world}
+out = {"workload": f"rmat-{scale}", "rows": n, "nnz": int(rp[-1]), "n_gpus": world, "chunks": chunks}
 for name, sr, a, b in [("sssp", MIN_PLUS_F32, 0.0, 0.0), ("bfs", OR_AND_I32, 1, 0)]:
     dt = np.int32 if sr == OR_AND_I32 else np.float32
     vals = va.astype(dt)
-    plan = ShardPlan(rp, ci, vals, rank, world)
+    plan = ShardPlan(rp, ci, vals, rank, world, chunks)
     step = HipLocalStep(plan, sr, local)
     x0 = np.zeros(n, dt)
     if sr == MIN_PLUS_F32:

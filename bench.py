@@ -263,8 +263,9 @@ def main():
         a, b = int(chk_rp[r]), int(chk_rp[r + 1])
         terms = x_host[chk_ci[a:b]].astype(np.float64) * chk_va[a:b].astype(np.float64)
         exact = terms.sum()
-        if (np.abs(terms).sum() >= 2 ** 24 and abs(y[r] - exact) <= 1e-5 * max(1.0, abs(exact))
-                and abs(y[r] - exact) <= abs(want[r] - exact)):
+        # (non-integer weights: every row rounds, in gold and on the GPU alike; the yardstick is then the exact dot)
+        if ((np.abs(terms).sum() >= 2 ** 24 or args.real_values) and abs(y[r] - exact) <= 1e-5 * max(1.0, abs(exact))
+                and (abs(y[r] - exact) <= abs(want[r] - exact) or args.real_values)):
             excused += 1
         else:
             bad += 1

@@ -661,6 +661,53 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   //    of all of it (speed only; correctness does not depend on placement).
   const int64_t chunk = std::max(1024, opt.chunk) & ~255;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
   const bool xcd_order = opt.xcd_order != 0;
+  // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).
+  // Skewed columns (a graph's hub columns fill a few tiles) would leave one XCD with most of the work while
+  // the workgroups dealt to the other seven return at once, so tiles are handed out by weight, heaviest first,
+  // to the least loaded XCD, and a tile heavier than an XCD's fair share is cut across several XCDs (home_of()
+  // then moves on to the next least loaded XCD after a fair share's worth of the tile's chunks).
+  // tile_segs[t]: (entries of the tile up to which the XCD applies, XCD), ascending
+  std::vector<std::vector<std::pair<int64_t, int>>> tile_segs((size_t)CT);
+  {
+    std::vector<int64_t> weight((size_t)CT, 0);
+    for (int t = 0; t < CT; t++) {
+      weight[(size_t)t] = hrel[(size_t)t];
+      for (int64_t sl = 0; sl < n_slabs; sl++) weight[(size_t)t] += run_len[(size_t)(sl * CT + t)];
+    }
+    const int64_t fair = std::max<int64_t>(chunk, H.stream_len / 8);
+    bool uniform = true;   // no tile far above the mean: keep the plain tile % 8 order
+    for (int t = 0; t < CT; t++) uniform = uniform && weight[(size_t)t] * CT <= 2 * H.stream_len + 2 * chunk * CT;
+    std::vector<int> order((size_t)CT);
+    for (int t = 0; t < CT; t++) order[(size_t)t] = t;
+    if (!uniform)
+      std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return weight[(size_t)a2] > weight[(size_t)b2]; });
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t : order) {
+      int64_t done = 0;
+      do {
+        int c = t & 7;
+        if (!uniform)
+          for (int k = 0; k < 8; k++) if (load[k] < load[c]) c = k;
+        const int64_t take = uniform ? weight[(size_t)t] : std::min(weight[(size_t)t] - done, fair);
+        load[c] += take;
+        done += take;
+        tile_segs[(size_t)t].emplace_back(done, c);
+      } while (done < weight[(size_t)t]);
+    }
+  }
+  // XCD list of the chunk that starts `before` entries into tile t
+  auto home_of = [&](int t, int64_t before) -> int {
+    if (!xcd_order) return 0;
+    for (const auto &sg : tile_segs[(size_t)t])
+      if (before < sg.first) return sg.second;
+    return tile_segs[(size_t)t].empty() ? (t & 7) : tile_segs[(size_t)t].back().second;
+  };
+  // entries of tile t that precede (slab sl, offset 0) / the tile's heavy run in the tile's own order: light runs, then heavy
+  auto tile_before = [&](int t, int64_t sl) -> int64_t {
+    int64_t n = 0;
+    for (int64_t k = 0; k < (sl < 0 ? n_slabs : sl); k++) n += run_len[(size_t)(k * CT + t)];
+    return n;
+  };
   std::vector<TileChunk> queue[8];
   H.need.assign((size_t)n_slabs * 2, 0);
   // cut one run into chunks
@@ -670,7 +717,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       const int64_t e0 = std::min<int64_t>(s0 + chunk, start + len);
       TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
                    (int32_t)(heavy ? 0 : pdelta[(size_t)slab]), slab, 0, 0};
-      per_xcd[xcd_order ? (t & 7) : 0].push_back(ch);
+      per_xcd[home_of(t, tile_before(t, slab) + (s0 - start))].push_back(ch);
     }
   };
   // append per-XCD lists to H.chunks so that position p holds a chunk of XCD p % 8 (empty fillers where a list is short)

@@ -332,7 +332,7 @@ struct TiledHost {
   int vdict_used = 0;
   int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values)
   std::vector<uint16_t> tcol, pslot;
-  int64_t stream_len = 0, p_len = 0, light_len = 0;
+  int64_t stream_len = 0, p_len = 0, light_len = 0, heavy_base = 0;
   int32_t n_partials = 0;
   // slabs: runs of consecutive bins whose products share one slot of the P ring
   std::vector<int32_t> slab_bin0;    // [n_slabs + 1] first bin of each slab
@@ -408,10 +408,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     if (is_heavy(r)) heavy_rows_idx.push_back(r);
   const int64_t n_heavy = (int64_t)heavy_rows_idx.size();
   std::vector<std::vector<Piece>> heavy_pieces((size_t)n_heavy);
-  auto parts_of = [](int64_t rel_start, int32_t padded) -> int32_t {   // 64-group blocks spanned
-    const int64_t g0 = rel_start / 4, g1 = (rel_start + padded) / 4 - 1;
-    return (int32_t)(g1 / 64 - g0 / 64 + 1);
-  };
   const int NT = build_threads(opt);
   struct Scratch { std::vector<int32_t> count, touched; std::vector<int64_t> pos; };
   std::vector<Scratch> scratch((size_t)NT);
@@ -514,10 +510,12 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int64_t hi = 0; hi < n_heavy; hi++) {
       int32_t np = 0;
       for (Piece &pc : heavy_pieces[(size_t)hi]) {
-        const int32_t padded = (pc.cnt + 3) & ~3;
+        const int32_t padded = (pc.cnt + HSTRIP - 1) / HSTRIP * HSTRIP;   // whole strips: one lane of phase 1 sums a strip
         pc.pos = hrel[(size_t)pc.tile];
         pc.part0 = np;
-        np += parts_of(pc.pos, padded);
+        // one partial per wave-part: the piece's strips spread over this many 64-strip blocks of the heavy run
+        const int64_t k0 = pc.pos / HSTRIP, k1 = (pc.pos + padded) / HSTRIP - 1;
+        np += (int32_t)(k1 / 64 - k0 / 64 + 1);
         hrel[(size_t)pc.tile] += padded;
       }
       H.heavy[(size_t)hi] = LongRow{(int32_t)heavy_rows_idx[(size_t)hi], (int32_t)slots, np, 0};
@@ -526,7 +524,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     }
     H.n_partials = (int32_t)slots;
   }
-  int64_t total = H.light_len;
+  int64_t total = (H.light_len + HSTRIP - 1) / HSTRIP * HSTRIP;   // heavy strips are read with 16- and 32-byte loads: keep them aligned
+  const int64_t heavy_base = total;
+  H.heavy_base = heavy_base;
   std::vector<int64_t> heavy_start(CT, 0);
   for (int t = 0; t < CT; t++) { heavy_start[t] = total; total += hrel[t]; }
   if (total > INT32_MAX - 8) return false;
@@ -592,7 +592,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   }
   else H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
-  H.gdest.assign((size_t)H.stream_len / 4, 0u);
+  H.gdest.assign((size_t)(H.stream_len - heavy_base) / HSTRIP + 1, 0u);   // partial slot of every heavy strip
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
   H.gsrc.assign((size_t)H.p_len / 4, 0u);
   auto put_entry = [&](int64_t pos, int32_t j) {
@@ -637,16 +637,16 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     const int64_t r = lr.row;
     Scratch &sc = scratch[(size_t)th];
     for (const Piece &pc : heavy_pieces[(size_t)hi]) {
-      const int32_t padded = (pc.cnt + 3) & ~3;
+      const int32_t padded = (pc.cnt + HSTRIP - 1) / HSTRIP * HSTRIP;
       const int64_t spos = heavy_start[(size_t)pc.tile] + pc.pos;
       int32_t part = lr.slot0 + pc.part0;
-      int64_t part_q0 = 0;                                         // where (in q) the current partial starts
-      for (int32_t q = 0; q < padded; q += 4) {
-        const int64_t grel = (pc.pos + q) / 4;                     // group index inside the tile's heavy run
-        if (q > 0 && grel % 64 == 0) { part++; part_q0 = q; }      // next wave of phase 1
-        const bool last = q + 4 >= padded || (grel + 1) % 64 == 0;
-        // partial slot of this group, groups of the same partial to its left, end-of-partial mark
-        H.gdest[(size_t)(spos + q) / 4] = (uint32_t)part | ((uint32_t)((q - part_q0) / 4) << GD_DIST_SHIFT) | (last ? GD_LAST : 0u);
+      int32_t part_q0 = 0;                                               // where (in q) the current partial starts
+      for (int32_t q = 0; q < padded; q += HSTRIP) {
+        const int64_t krel = (pc.pos + q) / HSTRIP;                      // strip index inside the tile's heavy run
+        if (q > 0 && krel % 64 == 0) { part++; part_q0 = q; }            // next wave of phase 1
+        const bool last = q + HSTRIP >= padded || (krel + 1) % 64 == 0;
+        H.gdest[(size_t)(spos + q - heavy_base) / HSTRIP] =
+            (uint32_t)part | ((uint32_t)((q - part_q0) / HSTRIP) << GD_DIST_SHIFT) | (last ? GD_LAST : 0u);
       }
       sc.pos[(size_t)pc.tile] = spos;
     }
@@ -659,7 +659,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
   //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
   //    of all of it (speed only; correctness does not depend on placement).
-  const int64_t chunk = std::max(1024, opt.chunk) & ~255;   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
+  const int64_t chunk = std::max(1024, opt.chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
   const bool xcd_order = opt.xcd_order != 0;
   // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).
   // Skewed columns (a graph's hub columns fill a few tiles) would leave one XCD with most of the work while
@@ -716,7 +716,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int64_t s0 = start; s0 < start + len; s0 += chunk) {
       const int64_t e0 = std::min<int64_t>(s0 + chunk, start + len);
       TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
-                   (int32_t)(heavy ? 0 : pdelta[(size_t)slab]), slab, 0, 0};
+                   (int32_t)(heavy ? H.heavy_base : pdelta[(size_t)slab]), slab, 0, 0};
       per_xcd[home_of(t, tile_before(t, slab) + (s0 - start))].push_back(ch);
     }
   };
@@ -1078,7 +1078,7 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
   if (streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
-                          ? (m->n_vdict ? 2ull : 6ull) * m->stream_len + (m->n_vdict ? (uint64_t)m->stream_len * m->code_bits / 8 : 0ull) + (uint64_t)(m->stream_len - m->light_len) /* gdest */ +
+                          ? (m->n_vdict ? 2ull : 6ull) * m->stream_len + (m->n_vdict ? (uint64_t)m->stream_len * m->code_bits / 8 : 0ull) + (uint64_t)(m->stream_len - m->light_len) / 4 /* gdest: 4 B per 16-entry strip */ +
                                 4ull * m->light_len /* P written */ + 7ull * m->light_len /* phase 2: P, slot, gsrc */ +
                                 vec /* x once: a tile is re-staged per phase-1 workgroup, but out of its XCD's L2 */
                           : 8ull * m->nnz + vec;
@@ -1290,6 +1290,14 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
 #endif
       return SH_OK;
     }
+#ifdef SH_STATS
+    static uint64_t *p1_stats = nullptr;
+    if (getenv("SH_STATS_DUMP")) {
+      if (!p1_stats) (void)hipMalloc((void **)&p1_stats, (size_t)1 << 22);
+      (void)hipMemsetAsync(p1_stats, 0, (size_t)1 << 22, e->stream);
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_p1_stats), &p1_stats, sizeof p1_stats, 0, hipMemcpyHostToDevice, e->stream);
+    }
+#endif
     // separate launches (SH_FUSED=0).  The heavy rows' (row, tile) sums first: they only feed the partials
     phase1(A->slab_chunk0[(size_t)n_slabs], A->slab_chunk0[(size_t)n_slabs + 1]);
     HIP_TRY(e, hipGetLastError());
@@ -1309,6 +1317,27 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
+#ifdef SH_STATS
+    if (getenv("SH_STATS_DUMP") && p1_stats) {
+      const int nch = A->n_chunks;
+      std::vector<uint64_t> hs((size_t)nch * 5);
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipMemcpy(hs.data(), p1_stats, hs.size() * 8, hipMemcpyDeviceToHost);
+      for (int kind = 0; kind < 2; kind++) {
+        double n = 0, ent = 0, stage = 0, total = 0;
+        uint64_t t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < nch; i++) {
+          const uint64_t *S = &hs[(size_t)i * 5];
+          if (S[1] == 0 || (int)S[0] != kind) continue;
+          n++; ent += S[1]; stage += (S[3] - S[2]) / 100.0; total += (S[4] - S[2]) / 100.0;
+          t0 = std::min(t0, S[2]); t1 = std::max(t1, S[4]);
+        }
+        if (n > 0)
+          fprintf(stderr, "[stats] phase 1 %s chunks: %.0f, %.0f entries each, staging %.2f us, whole chunk %.2f us (incl. store drain); span %.1f us\n",
+                  kind ? "heavy" : "light", n, ent / n, stage / n, total / n, (t1 - t0) / 100.0);
+      }
+    }
+#endif
     if (A->n_bins == 0 && A->n_tlong > 0) {   // every row is heavy: no phase 2 to host the sums
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_heavy_fixup<SR>), dim3(A->n_tlong), dim3(HFIX_BS), 0, e->stream, A->d_tlong,
                          A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);

@@ -30,6 +30,13 @@
 
 namespace sh {
 
+// SH_STATS builds (tools/, never the product): timelines of the tiled plan's launches
+#ifdef SH_STATS
+#define SH_STAT(...) __VA_ARGS__
+#else
+#define SH_STAT(...)
+#endif
+
 constexpr int BS = 256;          // 4 wave64 per workgroup
 constexpr int NNZ_BLK = 4096;    // products staged in LDS per stream block (16 KiB)
 constexpr int ROWS_BLK = 1024;   // max rows per stream block (row_ptr slice in LDS)
@@ -464,14 +471,23 @@ constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread i
 constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
 static_assert(TCOLS % 4 == 0 && TCOLS < 65536 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
-// gdest word of a heavy group: partial slot | (groups of the same partial to its left in the wave) << 25
-// | (last group of its partial) << 31
+// Heavy rows: every (row, tile) piece is padded to whole STRIPS of HSTRIP consecutive stream entries.  One
+// lane of phase 1 sums a strip (wide loads, 16 products in stream order); consecutive lanes whose strips
+// belong to the same piece are then combined by a segmented wave scan in DPP, and the last lane of each run
+// stores ONE partial per (row, tile, wave-part of 64 strips).  gdest[strip] = partial slot | (strips of the
+// same partial to its left in the wave) << 25 | (last strip of its partial) << 31: the plan builder knows
+// every split in advance, no key travels between lanes.  (History: the scan once ran per group of 4 entries
+// through ds_bpermute and made the heavy chunks -- 31 % of the entries of the power-law matrix, a third of
+// the bytes -- cost more than the light ones; one partial per strip without any scan left a 2.4 M-entry row
+// with 150 K partials for a single wave of phase 2 to add up: 0.60 instead of 0.49 ms.)
+constexpr int HSTRIP = 16;
 constexpr int GD_DIST_SHIFT = 25;
 constexpr uint32_t GD_SLOT_MASK = (1u << GD_DIST_SHIFT) - 1, GD_LAST = 0x80000000u;
 
 // entries [s,e) of the stream (slab-major light runs, then the tiles' heavy runs); positions >= hs
 // belong to heavy rows.  A light product at stream position q goes to P[q + pdelta] (the slab's slot
-// of the P ring); slab = -1 for heavy chunks.
+// of the P ring); slab = -1 for heavy chunks, whose pdelta is the stream position of the first heavy entry
+// (strip k of the heavy part covers entries [pdelta + 16 k, pdelta + 16 k + 16)).
 struct TileChunk { int32_t tile, s, e, hs, pdelta, slab, pad0, pad1; };
 // r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
 // n: products incl. padding; pstart: where the bin's slots / P sources start in pslot[] / gsrc[]
@@ -519,6 +535,7 @@ __device__ __forceinline__ typename SR::T seg_scan_wave(typename SR::T t, const 
 // VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
 // WT: products / partials are handed to other workgroups of the SAME launch: write-through stores
 //     (the caller drains and signals).  xs: [TCOLS + 4] words of LDS, ds: [VDICT].
+SH_STAT(__device__ uint64_t *g_p1_stats;)
 struct NoHook { __device__ void operator()() const {} };
 // staged(): called by every thread right after the barrier that publishes the x tile.  WT callers
 // signal the PREVIOUS chunk there: every wave has waited for its staging loads by then, and with
@@ -545,7 +562,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   if (tid == 0)
     xs[TCOLS] = ident;
   // Stage the x tile (cols is arbitrary, x is only guaranteed 4-byte aligned), then request the chunk's
-  // first stream batch.  (Requesting it right behind the staging loads, so that its HBM latency runs
+  // first stream batch.  (LDS-DMA staging -- global_load_lds_dwordx4, no VGPR round trip -- was measured
+  // neutral on the same box: 494-512 vs 494-497 us per SpMV.)  (Requesting it right behind the staging loads, so that its HBM latency runs
   // under the LDS writes, was measured SLOWER on the same box: 533 vs 508 us per SpMV.)
   // Every wave waits for staging loads here, and with them -- vmcnt counts in issue order -- for the
   // stores of the chunk it processed before: that is what lets a WT caller signal that chunk in staged().
@@ -638,62 +656,70 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       }
     }
   }
-  // ---- heavy entries (rows averaging >= 8 entries per tile): their products never travel
-  // through P.  Consecutive lanes whose groups share a partial slot are one (row, tile, wave-part)
-  // piece: segmented inclusive scan over the wave, the last lane of the piece stores the sum.  Wave
-  // boundaries are fixed by the stream position, so the plan builder knows every piece's split in
-  // advance and stores, per group, the slot, how far the piece reaches to the left and whether the
-  // group ends it (gdest): no key travels between lanes (deterministic, no atomics).
-  const int hb = max(ch.s, min(ch.e, ch.hs)) / 4, he = ch.e / 4;
-  const int lane = tid & 63;
+  // ---- heavy entries (rows averaging >= 8 entries per tile): their products never travel through P.
+  // One lane per strip of HSTRIP = 16 consecutive entries of one (row, tile) piece: wide loads (32 B of
+  // columns, 8 / 16 / 64 B of value codes / values, the strip's gdest word), 16 products summed in stream
+  // order, then the segmented wave scan over the strips of a piece; the last lane of a run stores the
+  // partial.  Wave boundaries are fixed by the stream position (chunks are cut at multiples of 64 strips
+  // from the heavy run's start), so the builder knows every split.  Deterministic, no atomics.
   if (ch.hs <= ch.s) {
-    constexpr int S = TBS * U;
-    auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U], uint32_t (&d)[U]) {
+    using SWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint4, uint2>::type>::type;
+    constexpr int NV = VC == 0 ? 4 : 1;   // SWords of values per strip: 4 x 16 B raw, 16 B of byte codes, 8 B of nibbles
+    const SWord *__restrict__ sval = reinterpret_cast<const SWord *>(tval_or_code);
+    const uint4 *__restrict__ scol = reinterpret_cast<const uint4 *>(tcol);
+    const int s0 = ch.s / HSTRIP, s1 = ch.e / HSTRIP, sbase = ch.pdelta / HSTRIP;   // strips of the chunk; first heavy strip
+    auto load = [&](int sid, SWord (&vw)[NV], uint4 (&c)[2], uint32_t &d) {
+      const int q = min(sid, s1 - 1);
 #pragma unroll
-      for (int k = 0; k < U; k++) {
-        const int g = max(hb, min(gbase + k * TBS, he - 1));
-        vw[k] = tval[g];
-        c[k] = tcol2[g];
-        d[k] = gdest[g];
-      }
+      for (int k = 0; k < NV; k++) vw[k] = sval[(size_t)q * NV + k];
+      c[0] = scol[(size_t)q * 2];
+      c[1] = scol[(size_t)q * 2 + 1];
+      d = gdest[q - sbase];
     };
-    auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U], const uint32_t (&d)[U]) {
+    const int lane = tid & 63;
+    auto consume = [&](int sid, const SWord (&vw)[NV], const uint4 (&c)[2], uint32_t d) {
+      const bool valid = sid < s1;
+      if (!__ballot(valid)) return;   // wave-uniform
+      const uint32_t cw[8] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w};
+      T t = SR::identity();
 #pragma unroll
-      for (int k = 0; k < U; k++) {
-        const int g = gbase + k * TBS;
-        const bool valid = g >= hb && g < he;
-        if (__ballot(valid)) {   // wave-uniform
-          T t = SR::identity();
-          if (valid) {
-            T pr[4];
-            products(vw[k], c[k], pr);
-            t = SR::add(SR::add(SR::add(pr[0], pr[1]), pr[2]), pr[3]);
-          }
-          // segmented inclusive scan, all in DPP (no LDS traffic: phase 1's LDS is busy gathering x)
-          t = seg_scan_wave<SR>(t, valid ? (int)((d[k] >> GD_DIST_SHIFT) & 63u) : 0, lane);
-          if (valid && (d[k] & GD_LAST)) {
-            if constexpr (WT) st_agent(partial + (d[k] & GD_SLOT_MASK), to_bits<T>(t));
-            else partial[d[k] & GD_SLOT_MASK] = to_bits<T>(t);
-          }
+      for (int i = 0; i < HSTRIP; i++) {
+        uint32_t v;
+        if constexpr (VC == 0) {
+          const uint4 w = vw[i / 4];
+          v = (i % 4 == 0) ? w.x : (i % 4 == 1) ? w.y : (i % 4 == 2) ? w.z : w.w;
+        } else if constexpr (VC == 1) {
+          const uint32_t w = (i / 4 == 0) ? vw[0].x : (i / 4 == 1) ? vw[0].y : (i / 4 == 2) ? vw[0].z : vw[0].w;
+          v = ds[(w >> (8 * (i % 4))) & 0xFFu];
+        } else {
+          const uint32_t w = (i / 8 == 0) ? vw[0].x : vw[0].y;
+          v = ds[(w >> (4 * (i % 8))) & 0xFu];
         }
+        const uint32_t col = (cw[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+        t = SR::add(t, SR::mul(from_bits<T>(xs[col]), from_bits<T>(v)));
+      }
+      if (!valid) t = SR::identity();   // (clamped reload of the chunk's last strip: must not join a run)
+      t = seg_scan_wave<SR>(t, valid ? (int)((d >> GD_DIST_SHIFT) & 63u) : 0, lane);
+      if (valid && (d & GD_LAST)) {
+        if constexpr (WT) st_agent(partial + (d & GD_SLOT_MASK), to_bits<T>(t));
+        else partial[d & GD_SLOT_MASK] = to_bits<T>(t);
       }
     };
-    VWord va[U], vb[U];
-    uint2 ca[U], cb[U];
-    uint32_t da[U], db[U];
-    // start on the 64-group boundary (relative to the chunk start) the builder assumed
-    int g0 = ch.s / 4 + ((hb - ch.s / 4) & ~63) + tid;
-    stage([&]() { load(g0, va, ca, da); });
-    if (g0 < he) {
+    SWord va[NV], vb[NV];
+    uint4 ca[2], cb[2];
+    uint32_t da = 0, db = 0;
+    int sid = s0 + tid;
+    stage([&]() { load(sid, va, ca, da); });
+    if (sid < s1) {
       for (;;) {
-        load(g0 + S, vb, cb, db);
-        consume(g0, va, ca, da);
-        g0 += S;
-        if (g0 >= he) break;
-        load(g0 + S, va, ca, da);
-        consume(g0, vb, cb, db);
-        g0 += S;
-        if (g0 >= he) break;
+        load(sid + TBS, vb, cb, db);
+        consume(sid, va, ca, da);
+        sid += TBS;
+        if (sid >= s1) break;
+        load(sid + TBS, va, ca, da);
+        consume(sid, vb, cb, db);
+        sid += TBS;
+        if (sid >= s1) break;
       }
     }
   }
@@ -711,8 +737,16 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e || (gate != nullptr && *gate == 0))
     return;   // filler that keeps the XCD-aligned chunk order / the iteration loop is over (StepDev::gate)
-#ifdef SH_FORCE_WT   // tuning builds: write-through stores in the separate launches too
-  tiled_phase1_chunk<SR, VC, true>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
+  SH_STAT(const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime(); __shared__ uint64_t st_staged;)
+  SH_STAT(auto stamp = [&]() { if (threadIdx.x == 0) st_staged = __builtin_amdgcn_s_memrealtime(); };)
+#ifdef SH_STATS
+  tiled_phase1_chunk<SR, VC, false>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial, stamp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && g_p1_stats) {   // per chunk: kind, entries, start, staged, end (100 MHz ticks)
+    uint64_t *S = g_p1_stats + (size_t)blockIdx.x * 5;
+    S[0] = ch.hs <= ch.s; S[1] = (uint64_t)(ch.e - ch.s); S[2] = st_t0; S[3] = st_staged; S[4] = __builtin_amdgcn_s_memrealtime();
+  }
 #else
   tiled_phase1_chunk<SR, VC, false>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
 #endif
@@ -782,12 +816,6 @@ struct P2Lds {
 // word the producers' atomics target delayed those atomics (and everything in-order behind them in
 // the producers' vmcnt) by tens of microseconds.  Polls back off to ~4 us.
 constexpr int GATE_WORDS = 64, GATE_FLAG = 32;
-// SH_STATS builds (tools/, never the product): per-workgroup timeline of the fused launch in D.stats
-#ifdef SH_STATS
-#define SH_STAT(...) __VA_ARGS__
-#else
-#define SH_STAT(...)
-#endif
 __device__ __forceinline__ uint32_t gate_arrive(uint32_t *gate) {   // returns the arrivals before this one
   return __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

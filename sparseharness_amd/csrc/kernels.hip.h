@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_fused(
     if (v < D.n_bins) {
       const int nb = (D.n_bins - v + N2 - 1) / N2;
       SH_STAT(uint64_t w = 0;)
-      SH_STAT(if (D.dbg & 2) { if (tid == 0) for (int j = 0; j < nb; j++) { const int sl = D.bins[v + j * N2].slab; uint32_t *g = gates + (D.n_slabs + sl) * GATE_WORDS;
+      SH_STAT(if (D.dbg & 2) { for (int j = tid; j < nb; j += P2S_BS) { const int sl = D.bins[v + j * N2].slab; uint32_t *g = gates + (D.n_slabs + sl) * GATE_WORDS;
                                  gate_finish(g, gate_arrive(g), (uint32_t)D.need[2 * sl + 1]); } } else)
       tiled_phase2_run<SR, true>(U.p2, D.bins, v, nb, N2, D.lrp, D.P, D.last_group, D.pslot, D.gsrc, nullptr, 0, 0, 1,
                                  nullptr, y, alpha, beta, use_y, out, st, gates, D.n_slabs, D.need, err SH_STAT(, &w, D.stats ? D.stats + 4096 : nullptr));

@@ -55,3 +55,32 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "libsh_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_plan_options_defaults_and_environment(monkeypatch):
+    """sh_plan_options: the defaults, and the SH_* environment read by sh_plan_options_from_env (no GPU needed)."""
+    lib = abi.load()
+    o = abi.sh_plan_options()
+    lib.sh_plan_options_default(C.byref(o))
+    assert (o.plan, o.autotune, o.value_coding, o.heavy_per_tile, o.xcd_order, o.fused, o.ring) == (0, 1, 0, 8, 1, 0, 3)
+    assert o.chunk == 32768 and o.slab_mb == 0
+    for k, v in {"SH_PLAN": "tiled", "SH_VALCODE": "off", "SH_AUTOTUNE": "0", "SH_FUSED": "1", "SH_SLAB_MB": "0.5",
+                 "SH_RING": "2", "SH_N2": "3", "SH_HEAVY_PER_TILE": "4", "SH_BUILD_THREADS": "2"}.items():
+        monkeypatch.setenv(k, v)
+    lib.sh_plan_options_from_env(C.byref(o))
+    assert (o.plan, o.value_coding, o.autotune, o.fused, o.ring, o.n2, o.heavy_per_tile, o.build_threads) == (2, -1, 0, 1, 2, 3, 4, 2)
+    assert o.slab_mb == 0.5
+    monkeypatch.setenv("SH_VALCODE", "8")
+    monkeypatch.setenv("SH_PLAN", "stream")
+    lib.sh_plan_options_from_env(C.byref(o))
+    assert (o.plan, o.value_coding) == (1, 8)
+
+
+def test_tiled_kernels_use_no_scratch_and_spill_nothing():
+    """The hand-scheduled loaders keep asm-issued loads in flight across compiler-visible code: only sound while
+    hipcc neither spills nor uses scratch in those kernels (make asm-check, sparseharness_amd/csrc)."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "sparseharness_amd", "csrc"), "asm-check"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
+    assert "0 offenders" in r.stdout

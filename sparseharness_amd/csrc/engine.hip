@@ -56,7 +56,8 @@ struct sh_csr {
   int32_t n_bins = 0;
   TileChunk *d_chunks = nullptr;
   int32_t n_chunks = 0;
-  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gsrc = nullptr, *d_P = nullptr;
+  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gblk = nullptr, *d_P = nullptr;
+  int32_t *d_ptab = nullptr;
   uint8_t *d_tcode = nullptr;    // value coding: one-byte dictionary codes instead of d_tval
   uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
   int n_vdict = 0;               // 0 = values stored raw
@@ -326,7 +327,8 @@ struct TiledHost {
   std::vector<RowBin> bins;
   std::vector<TileChunk> chunks;
   std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
-  std::vector<uint32_t> tval, gdest, gsrc, lrp;
+  std::vector<uint32_t> tval, gdest, gblk, lrp;   // gblk: per 64 groups of a bin {piece-start mask lo, hi, pieces started before, 0}
+  std::vector<int32_t> ptab;                      // per (bin, piece): P group index of the piece start - its group index inside the bin
   std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
   std::vector<uint32_t> vdict;       // empty = raw values
   int vdict_used = 0;
@@ -382,7 +384,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       r1++;
     RowBin b{};
     b.r0 = (int32_t)r; b.nr = (int32_t)(r1 - r); b.csr0 = (int32_t)light_off(r);
-    b.cnt = (int32_t)(light_off(r1) - light_off(r));
     H.bins.push_back(b);
     r = r1;
   }
@@ -398,7 +399,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   //                                 fixes where the 64-group wave boundaries of phase 1 fall, hence how
   //                                 a heavy (row, tile) piece splits into partials
   //      P3 (parallel)              value dictionary (per-thread sets, merged)
-  //      P4 (parallel, bins)        fill the light stream, pslot, gsrc
+  //      P4 (parallel, bins)        fill the light stream, pslot, the piece tables (gblk, ptab)
   //      P5 (parallel, heavy rows)  fill the heavy stream and gdest
   struct Piece { int32_t tile, cnt; int64_t pos; int32_t part0; };   // pos: stream position; part0: first partial (heavy)
   const int64_t n_bins = (int64_t)H.bins.size();
@@ -470,7 +471,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // S1: positions are relative to the (slab, tile) run until the run starts are known
   std::vector<int64_t> run_len((size_t)(n_slabs * CT), 0), run_start((size_t)(n_slabs * CT), 0), hrel(CT, 0);
   std::vector<int32_t> slab_of_bin((size_t)n_bins, 0);
-  int64_t p_off = 0;
+  int64_t p_off = 0, n_pieces_total = 0, n_blocks_total = 0;
   for (int64_t sl = 0; sl < n_slabs; sl++)
     for (int64_t bi = H.slab_bin0[(size_t)sl]; bi < H.slab_bin0[(size_t)sl + 1]; bi++) {
       RowBin &b = H.bins[(size_t)bi];
@@ -479,6 +480,10 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       if (p_off + b.n > INT32_MAX) return false;
       b.pstart = (int32_t)p_off;
       p_off += b.n;
+      b.pt0 = (int32_t)n_pieces_total;                         // its pieces in ptab[]
+      b.gb0 = (int32_t)n_blocks_total;                         // its 64-group blocks in gblk[]
+      n_pieces_total += (int64_t)bin_pieces[(size_t)bi].size();
+      n_blocks_total += std::max<int64_t>(1, (b.n / 4 + 63) / 64);
       for (Piece &pc : bin_pieces[(size_t)bi]) {
         int64_t &rl = run_len[(size_t)(sl * CT + pc.tile)];
         pc.pos = rl;
@@ -594,7 +599,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
   H.gdest.assign((size_t)(H.stream_len - heavy_base) / HSTRIP + 1, 0u);   // partial slot of every heavy strip
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
-  H.gsrc.assign((size_t)H.p_len / 4, 0u);
+  H.gblk.assign((size_t)(n_blocks_total + 1) * 4, 0u);
+  H.ptab.assign((size_t)n_pieces_total + 1, 0);
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
     const bool in_range = (uint32_t)c < (uint32_t)cols;
@@ -610,15 +616,32 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     const RowBin &b = H.bins[(size_t)bi];
     Scratch &sc = scratch[(size_t)th];
     int64_t off = b.pstart;
+    int32_t piece_k = 0;
     for (const Piece &pc : bin_pieces[(size_t)bi]) {
       const int32_t padded = (pc.cnt + 3) & ~3;
       const int64_t sl = slab_of_bin[(size_t)bi];
       const int64_t spos = run_start[(size_t)(sl * CT + pc.tile)] + pc.pos;
-      for (int32_t q = 0; q < padded; q += 4)
-        H.gsrc[(size_t)(off + q) / 4] = (uint32_t)(spos + q + pdelta[(size_t)sl]);   // where the group lies in the P ring
+      {
+        // where the piece lies in the P ring, as a group index relative to the piece's place in the bin: a group's
+        // P address is ptab[its piece] + its group index inside the bin.  gblk marks the group that starts a piece.
+        const int64_t g_in_bin = (off - b.pstart) / 4;
+        H.ptab[(size_t)b.pt0 + (size_t)piece_k] = (int32_t)((spos + pdelta[(size_t)sl]) / 4 - g_in_bin);
+        uint32_t *rec = &H.gblk[((size_t)b.gb0 + (size_t)(g_in_bin / 64)) * 4];
+        rec[(g_in_bin % 64) / 32] |= 1u << (g_in_bin % 32);
+        piece_k++;
+      }
       sc.pos[(size_t)pc.tile] = spos;        // next free stream position of this (bin, tile) piece
       sc.count[(size_t)pc.tile] = (int32_t)(off - spos);   // P position = stream position + this (fits: both < 2^31)
       off += padded;
+    }
+    {
+      const int64_t nblk = std::max<int64_t>(1, (b.n / 4 + 63) / 64);
+      uint32_t before = 0;
+      for (int64_t j = 0; j < nblk; j++) {
+        uint32_t *rec = &H.gblk[((size_t)b.gb0 + (size_t)j) * 4];
+        rec[2] = before;
+        before += (uint32_t)(__builtin_popcount(rec[0]) + __builtin_popcount(rec[1]));
+      }
     }
     for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
       if (is_heavy(r)) continue;
@@ -822,7 +845,7 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
   m->plan = (ok && ms[PLAN_STREAM] < 0.9f * ms[PLAN_TILED]) ? PLAN_STREAM : PLAN_TILED;
   if (m->plan == PLAN_STREAM) {   // the tiled layout is of no further use
     for (void **p : {(void **)&m->d_bins, (void **)&m->d_chunks, (void **)&m->d_tval, (void **)&m->d_tcol, (void **)&m->d_gdest,
-                     (void **)&m->d_pslot, (void **)&m->d_gsrc, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
+                     (void **)&m->d_pslot, (void **)&m->d_gblk, (void **)&m->d_ptab, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
                      (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_qchunks, (void **)&m->d_hchunks,
                      (void **)&m->d_lq0, (void **)&m->d_need, (void **)&m->d_ctl}) {
       if (*p) (void)hipFree(*p);
@@ -978,8 +1001,10 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_gsrc, th.gsrc.size() * 4 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_gsrc, th.gsrc.data(), th.gsrc.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_gblk, th.gblk.size() * 4 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_gblk, th.gblk.data(), th.gblk.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY_M(hipMalloc((void **)&m->d_ptab, th.ptab.size() * 4 + 16));
+    HIP_TRY_M(hipMemcpyAsync(m->d_ptab, th.ptab.data(), th.ptab.size() * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
     HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max<int64_t>(m->p_alloc, 4) * 4 + 16));
@@ -1046,7 +1071,7 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
-                  (void *)m->d_pslot, (void *)m->d_gsrc, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
+                  (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
                   (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_qchunks, (void *)m->d_hchunks, (void *)m->d_lq0,
                   (void *)m->d_need, (void *)m->d_ctl})
     if (p) (void)hipFree(p);
@@ -1079,7 +1104,7 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
                           ? (m->n_vdict ? 2ull : 6ull) * m->stream_len + (m->n_vdict ? (uint64_t)m->stream_len * m->code_bits / 8 : 0ull) + (uint64_t)(m->stream_len - m->light_len) / 4 /* gdest: 4 B per 16-entry strip */ +
-                                4ull * m->light_len /* P written */ + 7ull * m->light_len /* phase 2: P, slot, gsrc */ +
+                                4ull * m->light_len /* P written */ + 6ull * m->light_len + m->light_len / 6 /* phase 2: P, slot; piece tables ~0.14 B per product */ +
                                 vec /* x once: a tile is re-staged per phase-1 workgroup, but out of its XCD's L2 */
                           : 8ull * m->nnz + vec;
   }
@@ -1097,7 +1122,7 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     const int n_slabs = (int)m->slab_bin0.size() - 1;
     if (m->ring >= n_slabs) snprintf(slabs, sizeof slabs, "slabs=%d", n_slabs);
     else snprintf(slabs, sizeof slabs, "slabs=%d ring=%dx%.2fMB", n_slabs, m->ring, m->slab_cap * 4 / 1048576.0);
-    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM %s%s", vals,
+    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM pieces=table %s%s", vals,
              (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
              m->light_len / 1e6, slabs, m->fused ? " fused" : "");
   } else {
@@ -1240,7 +1265,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       D.tval = A->n_vdict ? (const void *)A->d_tcode : (const void *)A->d_tval;
       D.vdict = A->d_vdict; D.tcol = A->d_tcol; D.gdest = A->d_gdest; D.x = (const uint32_t *)x->d;
       D.P = A->d_P; D.p_bytes = (uint32_t)(A->p_alloc * 4); D.last_group = (int32_t)(A->p_alloc / 4 - 1);
-      D.partial = A->d_tpartial; D.bins = A->d_bins; D.lrp = A->d_lrp; D.pslot = A->d_pslot; D.gsrc = A->d_gsrc;
+      D.partial = A->d_tpartial; D.bins = A->d_bins; D.lrp = A->d_lrp; D.pslot = A->d_pslot; D.gblk = (const uint4 *)A->d_gblk; D.ptab = A->d_ptab;
       D.heavy_rows = A->d_tlong; D.need = A->d_need; D.ctl = A->d_ctl; D.err = (uint32_t *)(e->h_flag + 8);
 #ifdef SH_STATS
       static uint64_t *g_stats = nullptr;
@@ -1313,7 +1338,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       const bool last = sl1 == n_slabs;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(nb, e->n_cus)), dim3(P2S_BS), 0,
                          e->stream, A->d_bins + b0, nb, A->d_lrp, A->d_P, (int32_t)(A->p_alloc / 4 - 1), A->d_pslot,
-                         A->d_gsrc, A->d_tlong, last ? A->n_tlong : 0, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
+                         (const uint4 *)A->d_gblk, A->d_ptab, A->d_tlong, last ? A->n_tlong : 0, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
                          (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }

@@ -440,14 +440,14 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 //         inside the wave (segmented scan); one partial per run, no P traffic.
 //   phase 2  (persistent, wave-specialised: spmv_tiled_phase2s)
 //     per row bin of <= TBIN light products: loader waves gather the bin's
-//     (bin, tile) pieces from P (gsrc: where each group of 4 lies) and scatter
+//     (bin, tile) pieces from P (piece tables: where each group of 4 lies) and scatter
 //     them into an LDS image at their CSR slot (u16 per product); reducer waves
 //     sum the rows out of the previous image with the same code as the stream
 //     kernel above (deterministic order, same epilogue) and add up the heavy
 //     rows' partials.
 //
 // HBM bytes per light entry: 3 (coded) or 6 read + 4 written in phase 1,
-// 4 + 2 + 1 read in phase 2; per heavy entry 3.25 or 6.25 read -- against the
+// 4 + 2 + ~0.14 read in phase 2; per heavy entry ~2.8 or ~6.3 read -- against the
 // 8 B algorithmic, but all of it streamed.
 // ===========================================================================
 #ifndef SH_TCOLS
@@ -490,9 +490,10 @@ constexpr uint32_t GD_SLOT_MASK = (1u << GD_DIST_SHIFT) - 1, GD_LAST = 0x8000000
 // (strip k of the heavy part covers entries [pdelta + 16 k, pdelta + 16 k + 16)).
 struct TileChunk { int32_t tile, s, e, hs, pdelta, slab, pad0, pad1; };
 // r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
-// n: products incl. padding; pstart: where the bin's slots / P sources start in pslot[] / gsrc[]
-// (bin-major); slab: the slab (slot of the P ring) its products travel in.
-struct RowBin { int32_t r0, nr, csr0, cnt, n, pstart, slab, pad; };
+// n: products incl. padding; pstart: where the bin's slots start in pslot[] (bin-major); gb0 / pt0: its
+// first 64-group block in gblk[] / its first piece in ptab[]; slab: the slab (slot of the P ring) its
+// products travel in.
+struct RowBin { int32_t r0, nr, csr0, gb0, n, pstart, slab, pt0; };
 
 // Value coding (VC): when the matrix holds at most 256 distinct 4-byte values (always true for
 // pattern files, and for every file once the reference's int narrowing -- quirk A-3 -- has been
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
 // The prefetch of phase 2 goes through inline-asm loads.  hipcc tracks vmcnt only for loads it
 // emitted itself and is conservative across the loop back-edge: with compiler-visible loads it
 // drained the whole prefetch in front of the reduction, waited between the refills, and the P
-// addresses of the next bin depended on a gsrc load issued in the same iteration (~2 us per bin
+// addresses of the next bin depended on a source-index load issued in the same iteration (~2 us per bin
 // with nothing else in flight).  With asm loads the compiler inserts no waits for them at all;
 // the single hand-placed wait is phase2_wait_all() at the top of the loop, whose operand list
 // ties every prefetch register to it so that no use can be scheduled above it.
@@ -772,7 +773,7 @@ __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
 // ---------------------------------------------------------------------------------------------
 // Phase 2, wave-specialised (default).  One 1024-thread workgroup per CU; waves 0-3 are LOADERS,
 // waves 4-15 REDUCERS, and the LDS holds two product images:
-//   loaders   stream bin j+1 (P pieces via gsrc, slots) and scatter it into image (j+1)&1;
+//   loaders   stream bin j+1 (P pieces via the piece tables, slots) and scatter it into image (j+1)&1;
 //   reducers  reduce bin j out of image j&1 and write the rows.
 // Why: a CU sustains only what its miss queue holds per memory latency, so HBM time is lost
 // whenever no wave of the CU has a load to issue.  With every wave alternating between "stream
@@ -782,8 +783,8 @@ __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
 // two quarter-bin steps per thread, hand-scheduled: asm loads, one s_waitcnt vmcnt(8) per step --
 // and the reduction runs beside them on the other twelve.
 // Per-thread order of VMEM issue in the loaders (in-order return makes the wait a constant):
-//   step q:  wait vmcnt(8)  -> P/S(q) and gsrc(q+2) have landed, P/S(q+1) (8 loads) still fly
-//            scatter P/S(q) into the image; issue gsrc(q+3) (4 loads); issue P/S(q+2) (8 loads)
+//   step q:  wait vmcnt(8)  -> P/S(q) and the piece words of step q+2 have landed, P/S(q+1) (8 loads) still fly
+//            scatter P/S(q) into the image; request the piece words of q+3 (4 loads); issue P/S(q+2) (8 loads)
 // Barriers (s_barrier is workgroup-wide, so both roles execute the same two per bin): MID is the
 // one inside the reduction (list hand-over), END swaps the images.  While the loaders fill the
 // very first image the reducers have nothing to reduce: they add up the heavy rows' partials
@@ -855,7 +856,7 @@ template <class SR, bool FUSED>
 __device__ __forceinline__ void tiled_phase2_run(
     P2Lds &L, const RowBin *__restrict__ bins, const int b0, const int nb, const int stride,
     const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ P, int32_t last_group,
-    const uint16_t *__restrict__ pslot, const uint32_t *__restrict__ gsrc,
+    const uint16_t *__restrict__ pslot, const uint4 *__restrict__ gblk, const int32_t *__restrict__ ptab,
     const LongRow *__restrict__ heavy_rows, int32_t n_heavy, int32_t heavy_first, int32_t heavy_stride,
     const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
     typename SR::T beta, const bool use_y, uint32_t *__restrict__ out, const StepDev &st,
@@ -892,13 +893,37 @@ __device__ __forceinline__ void tiled_phase2_run(
         }
       }
     };
-    // addresses of step q = 4*j + quarter
-    auto issue_gs = [&](const RowBin &bn, int quarter, uint32_t (&g)[P2S_K]) {
-      const int n4 = max(bn.n / 4, 1);
-      const uint32_t *G4 = gsrc + bn.pstart / 4;
+    // Where the products of step q = 4*j + quarter lie in P.  The bin's groups are laid out piece by piece (one piece
+    // per column tile); instead of a source address per group (1 B per product of HBM traffic) the plan keeps, per
+    // 64 groups, a record {mask of the groups that start a piece, pieces started before the block} -- one scalar
+    // load per wave-instruction -- and per piece one word ptab = (P group index of the piece) - (its group index in
+    // the bin): a lane counts the piece starts up to its own group (mbcnt), gathers that word (a table of ~1.2 KB per
+    // bin: cache hits) and adds its group index.
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto record_of = [&](const RowBin &bn, int quarter, int k) -> uint4 {
+      const int nblk = max((bn.n / 4 + 63) / 64, 1);
+      const int blk = min(quarter * (P2S_Q / 64) + k * (P2S_LD / 64) + wave, nblk - 1);   // wave-uniform: a scalar load
+      return gblk[bn.gb0 + blk];
+    };
+    auto ptab_index = [&](const RowBin &bn, const uint4 rec) -> const int32_t * {
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi(rec.y, __builtin_amdgcn_mbcnt_lo(rec.x, 0u));
+      const uint32_t own = ((lane < 32 ? rec.x >> lane : rec.y >> (lane - 32)) & 1u);
+      return ptab + bn.pt0 + max((int)(rec.z + below + own) - 1, 0);
+    };
+    // The records of a step are fetched one step before its piece words are requested (a scalar load takes a few
+    // hundred cycles; asked for and used in the same step it cost 2 us per bin): rec[] always holds the records
+    // of the step whose words issue_gs() requests next.
+    uint4 rec[P2S_K];
+    auto fetch_rec = [&](const RowBin &bn, int quarter) {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++)
-        async_load(g[k], G4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
+        rec[k] = record_of(bn, quarter, k);
+    };
+    auto issue_gs = [&](const RowBin &bn, uint32_t (&g)[P2S_K]) {
+#pragma unroll
+      for (int k = 0; k < P2S_K; k++)
+        async_load(g[k], ptab_index(bn, rec[k]));
     };
     auto issue_ps = [&](const RowBin &bn, int quarter, const uint32_t (&g)[P2S_K], v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K]) {
       const int n4 = max(bn.n / 4, 1);
@@ -906,14 +931,15 @@ __device__ __forceinline__ void tiled_phase2_run(
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
         async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
-        // clamp: a stale register must not fault
+        // (clamped: a stale register must not fault)
+        const int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
 #if defined(SH_FORCE_WT)
-        async_load_sc1(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+        async_load_sc1(p[k], P4 + pg);
 #elif defined(SH_NO_SC1)
-        async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+        async_load(p[k], P4 + pg);
 #else
-        if constexpr (FUSED) async_load_sc1(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
-        else async_load(p[k], P4 + min((int32_t)(g[k] >> 2), last_group));
+        if constexpr (FUSED) async_load_sc1(p[k], P4 + pg);
+        else async_load(p[k], P4 + pg);
 #endif
       }
     };
@@ -944,17 +970,19 @@ __device__ __forceinline__ void tiled_phase2_run(
     v4u32 p[2][P2S_K];
     v2u32 sl[2][P2S_K];
     uint32_t g[2][P2S_K];
-    // prologue: gsrc(0), gsrc(1) by ordinary loads; then P/S(0), gsrc(2), P/S(1) in steady-state order
+    // prologue: the piece words of steps 0 and 1 by ordinary loads; then P/S(0), words(2), P/S(1) in steady-state order
     {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
         const RowBin &b1 = bin_of(1);
-        g[0][k] = (gsrc + cur.pstart / 4)[min(0 * P2S_Q + k * P2S_LD + tid, max(cur.n / 4, 1) - 1)];
-        g[1][k] = (gsrc + b1.pstart / 4)[min((1 % P2S_NS) * P2S_Q + k * P2S_LD + tid, max(b1.n / 4, 1) - 1)];
+        g[0][k] = (uint32_t)*ptab_index(cur, record_of(cur, 0, k));
+        g[1][k] = (uint32_t)*ptab_index(b1, record_of(b1, 1 % P2S_NS, k));
       }
       ensure(cur);
       issue_ps(cur, 0, g[0], p[0], sl[0]);
-      issue_gs(bin_of(2), 2 % P2S_NS, g[0]);
+      fetch_rec(bin_of(2), 2 % P2S_NS);
+      issue_gs(bin_of(2), g[0]);
+      fetch_rec(bin_of(3), 3 % P2S_NS);                    // (for the first step of the loop)
       issue_ps(bin_of(1), 1 % P2S_NS, g[1], p[1], sl[1]);
     }
     for (int j = 0; j <= nb; j++) {
@@ -963,9 +991,10 @@ __device__ __forceinline__ void tiled_phase2_run(
 #pragma unroll
         for (int s = 0; s < P2S_NS; s++) {
           const int a = s & 1;
-          wait8(p[a], sl[a], g[a]);                        // P/S(q) and gsrc(q+2) have landed
+          wait8(p[a], sl[a], g[a]);                        // P/S(q) and the piece words of q+2 have landed
           scatter(img, cur, s, p[a], sl[a]);
-          issue_gs(bin_of(s + 3), (s + 3) % P2S_NS, g[a ^ 1]);        // gsrc(q+3)
+          issue_gs(bin_of(s + 3), g[a ^ 1]);                          // piece words of step q+3 (records fetched a step ago)
+          fetch_rec(bin_of(s + 4), (s + 4) % P2S_NS);                 // records of step q+4
           if ((s + 2) % P2S_NS == 0)
             ensure(bin_of(s + 2));                         // first P load of the next bin
           issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
@@ -1065,7 +1094,7 @@ template <class SR>
 __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
     const RowBin *__restrict__ bins, int32_t n_bins, const int32_t *__restrict__ row_ptr,
     const uint32_t *__restrict__ P, int32_t last_group, const uint16_t *__restrict__ pslot,
-    const uint32_t *__restrict__ gsrc, const LongRow *__restrict__ heavy_rows, int32_t n_heavy,
+    const uint4 *__restrict__ gblk, const int32_t *__restrict__ ptab, const LongRow *__restrict__ heavy_rows, int32_t n_heavy,
     const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
     typename SR::T beta, int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   __shared__ P2Lds L;
@@ -1079,7 +1108,7 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
   if (b0 >= n_bins)
     return;
   const int nb = (n_bins - b0 + G - 1) / G;    // bins of this workgroup: b0, b0+G, ...
-  tiled_phase2_run<SR, false>(L, bins, b0, nb, G, row_ptr, P, last_group, pslot, gsrc, heavy_rows, n_heavy,
+  tiled_phase2_run<SR, false>(L, bins, b0, nb, G, row_ptr, P, last_group, pslot, gblk, ptab, heavy_rows, n_heavy,
                               (int)blockIdx.x * (P2S_RD / 64), G * (P2S_RD / 64), heavy_partial, y, alpha, beta,
                               use_y_i != 0, out, st, nullptr, 0, nullptr, nullptr);
 }
@@ -1122,7 +1151,8 @@ struct FusedDev {
   const RowBin *bins;
   const int32_t *lrp;
   const uint16_t *pslot;
-  const uint32_t *gsrc;
+  const uint4 *gblk;
+  const int32_t *ptab;
   const LongRow *heavy_rows;
   const int32_t *need;           // [2 * n_slabs]: {light chunks, bins} of each slab
   uint32_t *ctl;
@@ -1227,7 +1257,7 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_fused(
       SH_STAT(uint64_t w = 0;)
       SH_STAT(if (D.dbg & 2) { for (int j = tid; j < nb; j += P2S_BS) { const int sl = D.bins[v + j * N2].slab; uint32_t *g = gates + (D.n_slabs + sl) * GATE_WORDS;
                                  gate_finish(g, gate_arrive(g), (uint32_t)D.need[2 * sl + 1]); } } else)
-      tiled_phase2_run<SR, true>(U.p2, D.bins, v, nb, N2, D.lrp, D.P, D.last_group, D.pslot, D.gsrc, nullptr, 0, 0, 1,
+      tiled_phase2_run<SR, true>(U.p2, D.bins, v, nb, N2, D.lrp, D.P, D.last_group, D.pslot, D.gblk, D.ptab, nullptr, 0, 0, 1,
                                  nullptr, y, alpha, beta, use_y, out, st, gates, D.n_slabs, D.need, err SH_STAT(, &w, D.stats ? D.stats + 4096 : nullptr));
       SH_STAT(if (tid == 0) st_p2wait = w; __syncthreads(); st_wait = st_p2wait; st_items = nb;)
     }

@@ -677,3 +677,38 @@ def test_config2_scircuit_shaped_float_spmv(eng, plan, monkeypatch):
         for v in (xv, out):
             v.free()
     A.free()
+
+
+def test_fused_launch_hand_offs_under_slot_reuse_and_changing_inputs(eng, plan, monkeypatch):
+    """The experimental fused launch (SH_FUSED=1) hands products between workgroups INSIDE a launch (write-through
+    stores, gates, sc1 loads) and reuses every P slot many times per launch and across launches.  A stale or
+    early read would surface as a wrong row: twelve launches with twelve different x on a 2 M x 40 M power-law
+    matrix cut into ~40 slabs over a ring of 2, both value layouts, every row compared with the oracle."""
+    if plan != "tiled":
+        pytest.skip("the fused launch belongs to the tiled plan")
+    import os
+    if os.environ.get("SH_VALCODE") == "8":
+        pytest.skip("coded and raw values are enough here")
+    monkeypatch.setenv("SH_FUSED", "1")
+    monkeypatch.setenv("SH_SLAB_MB", "2")
+    monkeypatch.setenv("SH_RING", "2")
+    n = 2_000_000
+    rp, ci, va = H.powerlaw(n, 40_000_000, seed=21)
+    A = eng.upload_csr(n, n, rp, ci, va)
+    assert " fused" in A.describe() and "ring=2x" in A.describe(), A.describe()
+    out = eng.alloc(n).fill(0)
+    for k in range(12):
+        x = (1 + (np.arange(n) * (k + 3)) % (5 + k)).astype(np.float32)
+        xv = eng.vector(x)
+        eng.spmv(O.PLUS_TIMES_F32, A, xv, None, 1.0, 0.0, out)
+        got = out.download(np.float32)
+        want = O.gold_dot(rp, ci, va, x, 1.0)
+        big = np.diff(rp).astype(np.int64) * 16 * (5 + k) >= 2 ** 24       # rows whose float sum may round
+        np.testing.assert_array_equal(bits(got[~big]), bits(want[~big]))
+        for r in np.nonzero(big)[0]:   # hub rows: the sequential float gold itself rounds; the yardstick is the exact dot
+            a, b = int(rp[r]), int(rp[r + 1])
+            exact = float((x[ci[a:b]].astype(np.float64) * va[a:b].astype(np.float64)).sum())
+            assert abs(float(got[r]) - exact) <= REL * max(1.0, abs(exact)), (r, got[r], exact)
+        xv.free()
+    out.free()
+    A.free()

@@ -118,7 +118,7 @@ typedef struct sh_plan_options {
                               -1 off (raw 4-byte values)                                                      [SH_VALCODE]  */
   int32_t build_threads;   /* host threads of the layout build, 0 = min(hardware, 16)                         [SH_BUILD_THREADS] */
   int32_t heavy_per_tile;  /* rows averaging >= this many entries per column tile are pre-reduced in phase 1  [SH_HEAVY_PER_TILE] */
-  int32_t chunk;           /* entries per phase-1 work item                                                   [SH_CHUNK]    */
+  int32_t chunk;           /* entries per phase-1 work item, 0 = by the number of items per CU (48 K or 64 K)  [SH_CHUNK]    */
   int32_t xcd_order;       /* 1: phase-1 work items ordered so that an XCD stages only its eighth of x        [SH_XCD_ORDER] */
   int32_t fused;           /* 1: the tiled plan as ONE persistent launch with in-launch slab hand-offs
                               (experimental: measured slower than two launches)                    [SH_FUSED]    */

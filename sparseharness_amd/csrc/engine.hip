@@ -350,7 +350,7 @@ struct TiledHost {
 };
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
-                             const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, TiledHost &H) {
+                             const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
@@ -682,7 +682,21 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
   //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
   //    of all of it (speed only; correctness does not depend on placement).
-  const int64_t chunk = std::max(1024, opt.chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips   // smaller cuts for shard-sized streams were measured slower (x tile staging dominates)
+  // Entries per work item.  Every item stages a 128 KiB x tile (~2 us of a ~9 us item), so fewer, larger items cost
+  // less in total, but the launch ends with its slowest workgroup and a CU needs a handful of items to even out.
+  // Measured (equal cuts, 10 M / 200 M matrix and its 1/2, 1/4, 1/8 shards; profiles/r02_chunk_size_vs_shard_size.log):
+  // 64 K entries is best while the launch still has >= 6 items per CU (-3 % at full size), 48 K below that
+  // (-7 % on a 1/8 shard against 32 K).  opt.chunk > 0 overrides.
+  auto items_at = [&](int64_t c) {
+    int64_t n = 0;
+    for (int t = 0; t < CT; t++) {
+      for (int64_t sl = 0; sl < n_slabs; sl++) n += (run_len[(size_t)(sl * CT + t)] + c - 1) / c;
+      n += (hrel[(size_t)t] + c - 1) / c;
+    }
+    return n;
+  };
+  int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(65536) >= 6ll * std::max(n_cus, 1) ? 65536 : 49152);
+  chunk = std::max<int64_t>(1024, chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips
   const bool xcd_order = opt.xcd_order != 0;
   // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).
   // Skewed columns (a graph's hub columns fill a few tiles) would leave one XCD with most of the work while
@@ -736,8 +750,11 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // cut one run into chunks
   auto cut_run = [&](int t, int64_t start, int64_t len, int32_t slab, std::vector<TileChunk> (&per_xcd)[8]) {
     const bool heavy = slab < 0;
-    for (int64_t s0 = start; s0 < start + len; s0 += chunk) {
-      const int64_t e0 = std::min<int64_t>(s0 + chunk, start + len);
+    // equal cuts: a run of 56 K entries becomes 2 x 28 K, not 32 K + 24 K (the launch ends with its slowest workgroup)
+    const int64_t pieces = (len + chunk - 1) / chunk;
+    const int64_t cut = pieces > 0 ? std::min<int64_t>(chunk, ((len + pieces - 1) / pieces + 64 * HSTRIP - 1) & ~int64_t(64 * HSTRIP - 1)) : chunk;
+    for (int64_t s0 = start; s0 < start + len; s0 += cut) {
+      const int64_t e0 = std::min<int64_t>(s0 + cut, start + len);
       TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
                    (int32_t)(heavy ? H.heavy_base : pdelta[(size_t)slab]), slab, 0, 0};
       per_xcd[home_of(t, tile_before(t, slab) + (s0 - start))].push_back(ch);
@@ -869,7 +886,7 @@ void sh_plan_options_default(sh_plan_options *o) {
   memset(o, 0, sizeof *o);
   o->autotune = 1;
   o->heavy_per_tile = 8;
-  o->chunk = TCHUNK;
+  o->chunk = 0;   // auto (see build_tiled_plan)
   o->xcd_order = 1;
   o->ring = 3;
   o->n2 = 16;
@@ -967,7 +984,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   TiledHost th;
   m->plan = PLAN_STREAM;
   if (choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
-      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, th)) {
+      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th)) {
     m->plan = PLAN_TILED;
     m->n_bins = (int32_t)th.bins.size();
     m->n_chunks = (int32_t)th.chunks.size();

@@ -63,7 +63,7 @@ def test_plan_options_defaults_and_environment(monkeypatch):
     o = abi.sh_plan_options()
     lib.sh_plan_options_default(C.byref(o))
     assert (o.plan, o.autotune, o.value_coding, o.heavy_per_tile, o.xcd_order, o.fused, o.ring) == (0, 1, 0, 8, 1, 0, 3)
-    assert o.chunk == 32768 and o.slab_mb == 0
+    assert o.chunk == 0 and o.slab_mb == 0
     for k, v in {"SH_PLAN": "tiled", "SH_VALCODE": "off", "SH_AUTOTUNE": "0", "SH_FUSED": "1", "SH_SLAB_MB": "0.5",
                  "SH_RING": "2", "SH_N2": "3", "SH_HEAVY_PER_TILE": "4", "SH_BUILD_THREADS": "2"}.items():
         monkeypatch.setenv(k, v)

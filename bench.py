@@ -313,8 +313,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": (("sh::spmv_tiled_fused<PlusTimesF32> (one persistent launch)" if " fused" in layout else
-                                 "sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)") if A.plan()[0] == "tiled"
+                     "kernel": ("sh::spmv_tiled_phase1 + spmv_tiled_phase2s <PlusTimesF32> (one SpMV = these 2 launches)" if A.plan()[0] == "tiled"
                                 else "sh::spmv_csr_kernel<PlusTimesF32> (+ spmv_long_fixup)"),
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dev_ms_per_launch, 6),
                      "rank": rank, "rank_nnz": s_nnz},

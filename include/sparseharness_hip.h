@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SH_ABI_VERSION 1
+#define SH_ABI_VERSION 2   /* 2: sh_plan_options lost the fused-launch fields and gained `fold`; sh_csr_footprint, sh_plan_row_work */
 
 enum {
   SH_OK = 0,
@@ -120,11 +120,8 @@ typedef struct sh_plan_options {
   int32_t heavy_per_tile;  /* rows averaging >= this many entries per column tile are pre-reduced in phase 1  [SH_HEAVY_PER_TILE] */
   int32_t chunk;           /* entries per phase-1 work item, 0 = by the number of items per CU (48 K or 64 K)  [SH_CHUNK]    */
   int32_t xcd_order;       /* 1: phase-1 work items ordered so that an XCD stages only its eighth of x        [SH_XCD_ORDER] */
-  int32_t fused;           /* 1: the tiled plan as ONE persistent launch with in-launch slab hand-offs
-                              (experimental: measured slower than two launches)                    [SH_FUSED]    */
-  int32_t ring;            /* P ring slots (slabs reuse them; >= slab count: no reuse)                        [SH_RING]     */
-  int32_t n2;              /* fused: phase-2 workgroups per XCD (of CUs/8)                                    [SH_N2]       */
-  double slab_mb;          /* MiB of products per slab; huge = one slab                                       [SH_SLAB_MB]  */
+  int32_t fold;            /* 1: phase 1 folds the entries of one row inside one column tile into ONE product before
+                              it travels through P (a fifth of the light products of a power-law matrix)       [SH_FOLD]     */
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
@@ -139,12 +136,13 @@ int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
 /* Which execution plan sh_csr_upload chose (SH_PLAN=stream|tiled|auto overrides):
  * 0 = CSR-stream (x gathered from global memory, for L2-resident x),
  * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM).
- * streamed_bytes = HBM bytes one SpMV moves by construction under that plan (tiled: 3 or 6 B per
- * stream entry + 4 B written and 7 B re-read per light entry + the vectors; measured on the
- * headline matrix: 2.33 GB against 2.22 GB by this count). */
+ * streamed_bytes = HBM bytes one SpMV moves by construction under that plan (tiled: 2.5, 3 or 6 B per
+ * stream entry + 4 B written and ~6.2 B re-read per product that travels through P + the vectors; the
+ * measured figure of a layout is in profiles/measured_traffic.json). */
 int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
 /* One-line description of the layout built at upload, for logs and bench records, e.g.
- * "tiled values=dict4(16) tiles=306 chunks=6552 bins=8738 heavy_rows=5276 stream=206.4M light=137.9M".
+ * "tiled values=dict4(16) tiles=306 chunks=3420 bins=6750 heavy_rows=5276 stream=216M light=133.9M products=109M folded"
+ * (stream: entries phase 1 reads, padding included; light: entries of light rows; products: what travels through P).
  * values=dict8(k) / dict4(k): the matrix has k <= 256 / <= 16 distinct 4-byte values and the tiled stream
  * carries one-byte / four-bit codes (lossless; SH_VALCODE=8 stops at one-byte codes, SH_VALCODE=off keeps
  * raw values); values=raw otherwise.
@@ -152,6 +150,10 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes);
  * large matrices get the tiled plan by size; when their columns are local (row bins touch less than
  * half of the column tiles) both plans are timed and the CSR-stream plan is kept if > 10 % faster; SH_PLAN=stream|tiled or SH_AUTOTUNE=0 skip the timing. */
 int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen);
+/* Device memory the matrix holds (the arrays of the plan that runs; the CSR arrays themselves -- 8 B per entry --
+ * are uploaded only for the CSR-stream plan or while both plans are timed at upload).  The reference keeps its
+ * padded ELLPACK buffers for the life of the process (inc/harness.h:197-250, never released). */
+int sh_csr_footprint(const sh_csr *m, uint64_t *device_bytes);
 
 /* ---- vectors: replace createAndUploadGlobalArg / createGlobalArg /
  *      writeToGlobalArg / fillGlobalArg / readFromGlobalArg

@@ -25,8 +25,7 @@ class sh_launch(C.Structure):
 class sh_plan_options(C.Structure):
     """Plan options of sh_csr_upload_ex (field comments: include/sparseharness_hip.h)."""
     _fields_ = [("plan", C.c_int32), ("autotune", C.c_int32), ("value_coding", C.c_int32), ("build_threads", C.c_int32),
-                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fused", C.c_int32),
-                ("ring", C.c_int32), ("n2", C.c_int32), ("slab_mb", C.c_double)]
+                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32)]
 
 
 _vp, _i32, _i64, _u64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
@@ -53,6 +52,7 @@ SIGNATURES = {
     "sh_csr_algorithmic_bytes": (_int, [_vp, _int, C.POINTER(_u64)]),
     "sh_csr_plan": (_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
     "sh_csr_describe": (_int, [_vp, C.c_char_p, C.c_size_t]),
+    "sh_csr_footprint": (_int, [_vp, C.POINTER(_u64)]),
     "sh_vec_alloc": (_int, [_vp, _i64, _pp]),
     "sh_vec_wrap": (_int, [_vp, _vp, _i64, _pp]),
     "sh_vec_free": (_int, [_vp, _vp]),
@@ -100,7 +100,10 @@ def load():
         except ImportError:
             pass
     lib = C.CDLL(LIB_PATH)
+    partial = os.environ.get("SH_LIB") and os.environ.get("SH_LIB_PARTIAL") == "1"   # tools/ab_probe.py: older builds
     for name, (res, args) in SIGNATURES.items():
+        if partial and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

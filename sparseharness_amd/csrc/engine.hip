@@ -31,7 +31,7 @@ struct sh_engine {
   hipEvent_t ev_iter[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // sh_iterate: one per launch of a batch
   int32_t *d_flags = nullptr;   // per-iteration convergence flags
   int32_t n_flags = 0;
-  int32_t *h_flag = nullptr;    // pinned, 64 B: [0] convergence flag read-back, [8] give-up word of the fused launch
+  int32_t *h_flag = nullptr;    // pinned, 64 B: convergence flags of a batch of iterations, read back
   char name[256] = {0};
   int n_cus = 256;
   std::string err;
@@ -56,7 +56,7 @@ struct sh_csr {
   int32_t n_bins = 0;
   TileChunk *d_chunks = nullptr;
   int32_t n_chunks = 0;
-  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gblk = nullptr, *d_P = nullptr;
+  uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gblk = nullptr, *d_P = nullptr, *d_obase = nullptr;
   int32_t *d_ptab = nullptr;
   uint8_t *d_tcode = nullptr;    // value coding: one-byte dictionary codes instead of d_tval
   uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
@@ -68,19 +68,10 @@ struct sh_csr {
   int32_t n_tlong = 0;
   uint32_t *d_tpartial = nullptr;
   int32_t *d_lrp = nullptr;     // light row offsets, bit 31 = heavy row
-  int64_t light_len = 0;
-  int64_t stream_len = 0, p_len = 0;
-  // slabs of the tiled plan (host copies: launch geometry)
-  std::vector<int32_t> slab_bin0, slab_chunk0;
-  int64_t slab_cap = 0, p_alloc = 0;   // products per ring slot / in P
-  int32_t ring = 1;
-  // fused launch (spmv_tiled_fused): work queues, per-slab needs, control block
-  bool fused = false;
-  int32_t n2 = 0;               // phase-2 workers per XCD slot
-  TileChunk *d_qchunks = nullptr, *d_hchunks = nullptr;
-  int32_t *d_lq0 = nullptr, *d_need = nullptr;
-  uint32_t *d_ctl = nullptr;
-  int32_t n_hchunks = 0, ctl_words = 0;
+  int64_t light_len = 0, light_entries = 0;   // light part of the stream (padding included) / light entries of the matrix
+  int64_t stream_len = 0, p_len = 0;          // stream entries in all / products in P
+  int fold = 0;                               // phase 1 folds a row's entries inside a tile into one product
+  size_t stream_bytes = 0, tiled_bytes = 0;   // device memory held by the arrays of plan A / plan B
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
 
@@ -163,16 +154,6 @@ struct ValSet {
     list.push_back(b);
   }
 };
-
-// After a stream synchronisation: did a fused launch give up on a hand-off (bounded spins, kernels.hip.h)?
-static int check_gave_up(sh_engine *e) {
-  if (e->h_flag && e->h_flag[8]) {
-    e->h_flag[8] = 0;
-    return fail(e, SH_EHIP, "a fused SpMV launch gave up waiting for a slab hand-off (not all workgroups resident? "
-                            "another kernel sharing the GPU?): results are invalid; SH_FUSED=0 uses separate launches");
-  }
-  return SH_OK;
-}
 
 extern "C" {
 
@@ -272,7 +253,7 @@ int sh_engine_synchronize(sh_engine *e) {
   if (!e)
     return SH_EINVAL;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return check_gave_up(e);
+  return SH_OK;
 }
 
 // ---------------------------------------------------------------- matrix
@@ -318,40 +299,50 @@ static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t>
 
 
 // ---- x-tiled two-phase plan (see kernels.hip.h) ---------------------------
-// Host-side layout construction.  CSR order is already (bin, slot) order, so
-// the tile-major stream is a stable partition of the entries by column tile;
-// every (bin, tile) piece is padded to a multiple of 4 entries so that one
-// thread's 16-byte group never straddles pieces and its 4 products land at 4
-// consecutive, 16-byte aligned positions of P.
+// Host-side layout construction.  The tile-major stream is a partition of the light entries by
+// column tile and, inside a tile, by row bin; inside a (bin, tile) piece the entries of one row
+// form a RUN (at most 4 entries; longer ones are cut) that phase 1 folds into ONE product, and
+// runs are packed into whole groups of 4 entries (one lane of phase 1) so that no run straddles
+// a group.  Every piece is a whole number of groups and yields a multiple of 4 products, so a
+// piece starts 16-byte aligned in P.
 struct TiledHost {
   std::vector<RowBin> bins;
   std::vector<TileChunk> chunks;
   std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
-  std::vector<uint32_t> tval, gdest, gblk, lrp;   // gblk: per 64 groups of a bin {piece-start mask lo, hi, pieces started before, 0}
+  std::vector<uint32_t> tval, gdest, gblk, lrp, obase;   // gblk: per 64 product groups of a bin {piece-start mask lo, hi, pieces started before, 0}
   std::vector<int32_t> ptab;                      // per (bin, piece): P group index of the piece start - its group index inside the bin
   std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
   std::vector<uint32_t> vdict;       // empty = raw values
   int vdict_used = 0;
   int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values)
   std::vector<uint16_t> tcol, pslot;
-  int64_t stream_len = 0, p_len = 0, light_len = 0, heavy_base = 0;
+  int64_t stream_len = 0, p_len = 0, light_len = 0, heavy_base = 0;   // light_len: light stream entries (padding included); p_len: products in P
+  int64_t light_entries = 0;         // light entries of the matrix (no padding)
   int32_t n_partials = 0;
-  // slabs: runs of consecutive bins whose products share one slot of the P ring
-  std::vector<int32_t> slab_bin0;    // [n_slabs + 1] first bin of each slab
-  std::vector<int32_t> slab_chunk0;  // [n_slabs + 2] first phase-1 chunk of each slab; the last range holds the heavy chunks
-  int64_t slab_cap = 0;              // products per ring slot
-  int32_t ring = 1;                  // ring slots (>= n_slabs: every slab has addresses of its own)
-  // the fused launch's work queues: light chunks per XCD slot (slab-major, no fillers), heavy chunks,
-  // and per slab {light chunks, bins}
-  std::vector<TileChunk> qchunks, hchunks;
-  int32_t lq0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  std::vector<int32_t> need;
   double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
 };
+
+// How the runs of one (bin, tile) piece -- n4 of 4 entries, n3 of 3, n2 of 2, n1 singles -- pack into groups of 4
+// entries: a 4 alone, a 3 with a single (while there are any), 2s in pairs (an odd one with up to two singles),
+// the other singles four to a group.  Free positions are padding entries; a padding entry either joins the run
+// in front of it (no product of its own) or is a run of its own (a padding product): as many of them as bring the
+// piece's products to a multiple of 4, in one more group if the free positions do not suffice.
+struct PiecePack { int32_t groups, products; };
+static PiecePack pack_piece(int64_t n4, int64_t n3, int64_t n2, int64_t n1) {
+  int64_t s = n1, G = n4 + n3;
+  s -= std::min(n3, s);
+  G += n2 / 2;
+  if (n2 & 1) { G++; s -= std::min<int64_t>(s, 2); }
+  G += (s + 3) / 4;
+  const int64_t E = 4 * n4 + 3 * n3 + 2 * n2 + n1, R = n4 + n3 + n2 + n1, need = (-R) & 3;
+  if (need > 4 * G - E) G++;
+  return PiecePack{(int32_t)G, (int32_t)(R + need)};
+}
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
+  const bool fold = opt.fold != 0;
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
   const int64_t per_tile = std::max(1, opt.heavy_per_tile);
@@ -359,23 +350,61 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)rp[r + 1] - rp[r] >= heavy_thr; };
   auto tile_of = [&](int32_t c) -> int { return ((uint32_t)c < (uint32_t)cols) ? (c / TCOLS) : 0; };
+  const int NT = build_threads(opt);
 
-  // 1. light row offsets (heavy rows have light length 0 and carry bit 31) and row bins
+  // Per-thread scratch.  ent[]: the light entries of the bin being worked on, as (tile << 32 | local row << 16 ...)
+  // would not fit: two parallel arrays sorted by tile with a counting sort (stable: row order, then CSR order).
+  struct Scratch {
+    std::vector<int32_t> count, touched;            // per tile
+    std::vector<int64_t> pos;                       // per tile
+    std::vector<int32_t> e_row, e_j, s_row, s_j;    // entries of a bin: unsorted / sorted by tile
+    std::vector<int32_t> start;                     // per touched tile: first entry in s_*
+    std::vector<uint16_t> rt;                       // tiles of one row (products per row)
+    std::vector<int32_t> row_next;                  // per row of the bin: next product index inside the row
+    std::vector<int32_t> l4, l3, l2, l1;            // runs of a piece by length (index of the first entry in s_*)
+  };
+  std::vector<Scratch> scratch((size_t)NT);
+  for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
+
+  // 1. products per light row (= its length without folding; with folding sum over tiles of ceil(entries in the tile / 4)),
+  //    light row offsets in products (heavy rows have light length 0 and carry bit 31) and row bins
   H.lrp.assign((size_t)rows + 1, 0u);
   {
+    std::vector<int32_t> nprod((size_t)rows, 0);
+    parallel_items((rows + 4095) / 4096, 4, NT, [&](int64_t blk, int th) {
+      Scratch &sc = scratch[(size_t)th];
+      for (int64_t r = blk * 4096; r < std::min(rows, (blk + 1) * 4096); r++) {
+        if (is_heavy(r)) continue;
+        const int32_t d = rp[r + 1] - rp[r];
+        if (!fold || d <= 1) { nprod[(size_t)r] = d; continue; }
+        sc.rt.clear();
+        for (int32_t j = rp[r]; j < rp[r + 1]; j++) sc.rt.push_back((uint16_t)tile_of(ci[j]));
+        std::sort(sc.rt.begin(), sc.rt.end());
+        int32_t n = 0;
+        for (size_t i = 0; i < sc.rt.size();) {
+          size_t k = i + 1;
+          while (k < sc.rt.size() && sc.rt[k] == sc.rt[i]) k++;
+          n += (int32_t)((k - i + 3) / 4);
+          i = k;
+        }
+        nprod[(size_t)r] = n;
+      }
+    });
     uint32_t acc = 0;
+    int64_t le = 0;
     for (int64_t r = 0; r < rows; r++) {
       const bool hv = is_heavy(r);
       H.lrp[(size_t)r] = acc | (hv ? 0x80000000u : 0u);
-      if (!hv) acc += (uint32_t)(rp[r + 1] - rp[r]);
+      if (!hv) { acc += (uint32_t)nprod[(size_t)r]; le += rp[r + 1] - rp[r]; }
     }
     H.lrp[(size_t)rows] = acc;
+    H.light_entries = le;
   }
   auto light_off = [&](int64_t r) { return (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu); };
   // Bins are filled up to TBIN products.  (Sizing them so that every CU gets the same number of
   // bins was tried for shard-sized matrices: the smaller (bin, tile) pieces cost more than the
   // ragged last round saves -- 0.115 vs 0.105 ms on a 1/8 shard in round 1, 0.076 vs 0.075 ms with round 2's kernels.)
-  // every (bin, tile) piece is padded to 4: leave room so that a padded bin never exceeds TBIN
+  // every (bin, tile) piece is padded to 4 products: leave room so that a padded bin never exceeds TBIN
   // (phase 2 prefetches exactly TBIN products per bin into registers)
   int64_t bin_target = std::max<int64_t>(TBIN / 4, (int64_t)TBIN - 3ll * CT);   // cnt + 3*min(CT,cnt) <= TBIN
   for (int64_t r = 0; r < rows;) {
@@ -389,19 +418,20 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   }
 
   // 2.-3. The layout.  Each tile's stream is [light pieces, bins in order][heavy pieces, rows in
-  //    order]; every piece is padded to groups of 4.  Built in passes so that the O(nnz) walks run on
-  //    several host threads (work items handed out dynamically; each writes only its own bin's or
-  //    row's ranges) and only O(pieces) prefix sums stay sequential:
-  //      P1 (parallel, bins)        count each bin's entries per tile -> its piece list, bin.n
-  //      P2 (parallel, heavy rows)  the same per heavy row
-  //      S1 (sequential)            bin.pstart, per-tile totals; position of every light piece
+  //    order].  Built in passes so that the O(nnz) walks run on several host threads (work items handed
+  //    out dynamically; each writes only its own bin's or row's ranges) and only O(pieces) prefix sums
+  //    stay sequential:
+  //      P1 (parallel, bins)        sort each bin's entries by tile, find the runs -> its piece list (groups, products), bin.n
+  //      P2 (parallel, heavy rows)  entries per tile of each heavy row
+  //      S1 (sequential)            bin.pstart, per-tile totals; stream / P position of every light piece
   //      S2 (sequential)            heavy pieces: hrel[t] is the running position inside tile t, which
   //                                 fixes where the 64-group wave boundaries of phase 1 fall, hence how
   //                                 a heavy (row, tile) piece splits into partials
   //      P3 (parallel)              value dictionary (per-thread sets, merged)
-  //      P4 (parallel, bins)        fill the light stream, pslot, the piece tables (gblk, ptab)
+  //      P4 (parallel, bins)        fill the light stream (entries + fold flags), pslot, the piece tables (gblk, ptab)
   //      P5 (parallel, heavy rows)  fill the heavy stream and gdest
-  struct Piece { int32_t tile, cnt; int64_t pos; int32_t part0; };   // pos: stream position; part0: first partial (heavy)
+  //      P6 (parallel, tiles)       obase: where in P the products of every 64 stream groups start
+  struct Piece { int32_t tile, cnt, groups, prods; int64_t pos, ppos; int32_t part0; };   // pos / ppos: stream / P position; part0: first partial (heavy)
   const int64_t n_bins = (int64_t)H.bins.size();
   std::vector<std::vector<Piece>> bin_pieces((size_t)n_bins);
   std::vector<int64_t> heavy_rows_idx;
@@ -409,104 +439,106 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     if (is_heavy(r)) heavy_rows_idx.push_back(r);
   const int64_t n_heavy = (int64_t)heavy_rows_idx.size();
   std::vector<std::vector<Piece>> heavy_pieces((size_t)n_heavy);
-  const int NT = build_threads(opt);
-  struct Scratch { std::vector<int32_t> count, touched; std::vector<int64_t> pos; };
-  std::vector<Scratch> scratch((size_t)NT);
-  for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
-  // pieces of the rows [ra, rb) that satisfy `want` (light / heavy), tiles ascending
-  auto collect = [&](Scratch &sc, int64_t ra, int64_t rb, bool want_heavy, std::vector<Piece> &out) {
-    sc.touched.clear();
-    for (int64_t r = ra; r < rb; r++) {
-      if (is_heavy(r) != want_heavy) continue;
+  // the light entries of bin b sorted by tile (stable): sc.s_row / sc.s_j, tiles in sc.touched (ascending), first entry of
+  // touched tile k in sc.start[k] (sc.start has one more element: the total)
+  auto sort_bin = [&](Scratch &sc, const RowBin &b) {
+    sc.touched.clear(); sc.e_row.clear(); sc.e_j.clear();
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
+      if (is_heavy(r)) continue;
       for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
         const int t = tile_of(ci[j]);
         if (sc.count[(size_t)t]++ == 0) sc.touched.push_back(t);
+        sc.e_row.push_back((int32_t)(r - b.r0));
+        sc.e_j.push_back(j);
       }
     }
     std::sort(sc.touched.begin(), sc.touched.end());
-    out.clear();
-    out.reserve(sc.touched.size());
-    for (int t : sc.touched) {
-      out.push_back(Piece{t, sc.count[(size_t)t], 0, 0});
-      sc.count[(size_t)t] = 0;
+    sc.start.clear();
+    int32_t acc = 0;
+    for (int t : sc.touched) { sc.start.push_back(acc); sc.pos[(size_t)t] = acc; acc += sc.count[(size_t)t]; }
+    sc.start.push_back(acc);
+    sc.s_row.resize(sc.e_row.size()); sc.s_j.resize(sc.e_row.size());
+    for (size_t i = 0; i < sc.e_row.size(); i++) {
+      const int64_t q = sc.pos[(size_t)tile_of(ci[sc.e_j[i]])]++;
+      sc.s_row[(size_t)q] = sc.e_row[i]; sc.s_j[(size_t)q] = sc.e_j[i];
+    }
+    for (int t : sc.touched) sc.count[(size_t)t] = 0;   // scratch back to all-zero
+  };
+  // the runs of the entries [a, e) of sc.s_* (one tile): same row, at most 4 entries (1 without folding), by length
+  auto find_runs = [&](Scratch &sc, int32_t a, int32_t e) {
+    sc.l4.clear(); sc.l3.clear(); sc.l2.clear(); sc.l1.clear();
+    for (int32_t i = a; i < e;) {
+      int32_t k = i + 1;
+      if (fold) while (k < e && k - i < 4 && sc.s_row[(size_t)k] == sc.s_row[(size_t)i]) k++;
+      (k - i == 4 ? sc.l4 : k - i == 3 ? sc.l3 : k - i == 2 ? sc.l2 : sc.l1).push_back(i);
+      i = k;
     }
   };
   // P1
   parallel_items(n_bins, 8, NT, [&](int64_t bi, int th) {
     RowBin &b = H.bins[(size_t)bi];
-    collect(scratch[(size_t)th], b.r0, (int64_t)b.r0 + b.nr, false, bin_pieces[(size_t)bi]);
+    Scratch &sc = scratch[(size_t)th];
+    sort_bin(sc, b);
+    auto &out = bin_pieces[(size_t)bi];
+    out.clear();
+    out.reserve(sc.touched.size());
     int64_t n = 0;
-    for (const Piece &pc : bin_pieces[(size_t)bi]) n += (pc.cnt + 3) & ~3;
+    for (size_t k = 0; k < sc.touched.size(); k++) {
+      find_runs(sc, sc.start[k], sc.start[k + 1]);
+      const PiecePack pk = pack_piece((int64_t)sc.l4.size(), (int64_t)sc.l3.size(), (int64_t)sc.l2.size(), (int64_t)sc.l1.size());
+      out.push_back(Piece{sc.touched[k], sc.start[k + 1] - sc.start[k], pk.groups, pk.products, 0, 0, 0});
+      n += pk.products;
+    }
     b.n = (int32_t)n;
   });
   // P2
   parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
     const int64_t r = heavy_rows_idx[(size_t)hi];
-    collect(scratch[(size_t)th], r, r + 1, true, heavy_pieces[(size_t)hi]);
+    Scratch &sc = scratch[(size_t)th];
+    sc.touched.clear();
+    for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
+      const int t = tile_of(ci[j]);
+      if (sc.count[(size_t)t]++ == 0) sc.touched.push_back(t);
+    }
+    std::sort(sc.touched.begin(), sc.touched.end());
+    auto &out = heavy_pieces[(size_t)hi];
+    out.clear();
+    out.reserve(sc.touched.size());
+    for (int t : sc.touched) {
+      out.push_back(Piece{t, sc.count[(size_t)t], 0, 0, 0, 0, 0});
+      sc.count[(size_t)t] = 0;
+    }
   });
-  // Slabs: consecutive bins up to slab_cap products.  The stream is slab-major -- [slab 0: tile 0's
-  // pieces of the slab's bins, tile 1's, ...][slab 1: ...]...[heavy pieces, tile-major] -- so that phase 2 of
-  // a slab can run right behind phase 1 of the same slab and P only ever holds `ring` slabs: a
-  // product is re-read (and its line overwritten by a later slab) while it is still in the 256 MiB
-  // Infinity Cache (profiles/r02_lab_slab_mall_ring_microbench.log: the same bytes move at 7.9 instead
-  // of 5.3 TB/s).  P position of a light entry = its stream position + the slab's pdelta.
-  {
-    // default: one slab, P linear (two launches).  SH_SLAB_MB / SH_RING cut slabs and reuse P slots: that is
-    // what the fused launch (SH_FUSED=1) is built around.
-    const double cap_mb = opt.slab_mb > 0 ? opt.slab_mb : 1e9;
-    H.slab_cap = std::max<int64_t>(TBIN, (int64_t)std::min(cap_mb * 262144.0, 2e9)) & ~int64_t(3);
-    H.ring = std::max(1, opt.ring);
-    int64_t acc = 0;
-    H.slab_bin0.push_back(0);
-    for (int64_t bi = 0; bi < n_bins; bi++) {
-      const int64_t n = H.bins[(size_t)bi].n;
-      if (n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
-      if (acc > 0 && acc + n > H.slab_cap) { H.slab_bin0.push_back((int32_t)bi); acc = 0; }
-      acc += n;
-    }
-    H.slab_bin0.push_back((int32_t)n_bins);
-  }
-  const int64_t n_slabs = (int64_t)H.slab_bin0.size() - 1;
-  if (n_slabs <= H.ring) H.ring = (int32_t)std::max<int64_t>(1, n_slabs);   // linear: no slot is reused
-  // S1: positions are relative to the (slab, tile) run until the run starts are known
-  std::vector<int64_t> run_len((size_t)(n_slabs * CT), 0), run_start((size_t)(n_slabs * CT), 0), hrel(CT, 0);
-  std::vector<int32_t> slab_of_bin((size_t)n_bins, 0);
+  // S1: positions are relative to the tile's light run until the run starts are known
+  std::vector<int64_t> run_len((size_t)CT, 0), run_plen((size_t)CT, 0), run_start((size_t)CT, 0), run_pstart((size_t)CT, 0), hrel(CT, 0);
   int64_t p_off = 0, n_pieces_total = 0, n_blocks_total = 0;
-  for (int64_t sl = 0; sl < n_slabs; sl++)
-    for (int64_t bi = H.slab_bin0[(size_t)sl]; bi < H.slab_bin0[(size_t)sl + 1]; bi++) {
-      RowBin &b = H.bins[(size_t)bi];
-      slab_of_bin[(size_t)bi] = (int32_t)sl;
-      b.slab = (int32_t)sl;
-      if (p_off + b.n > INT32_MAX) return false;
-      b.pstart = (int32_t)p_off;
-      p_off += b.n;
-      b.pt0 = (int32_t)n_pieces_total;                         // its pieces in ptab[]
-      b.gb0 = (int32_t)n_blocks_total;                         // its 64-group blocks in gblk[]
-      n_pieces_total += (int64_t)bin_pieces[(size_t)bi].size();
-      n_blocks_total += std::max<int64_t>(1, (b.n / 4 + 63) / 64);
-      for (Piece &pc : bin_pieces[(size_t)bi]) {
-        int64_t &rl = run_len[(size_t)(sl * CT + pc.tile)];
-        pc.pos = rl;
-        rl += (pc.cnt + 3) & ~3;
-      }
+  for (int64_t bi = 0; bi < n_bins; bi++) {
+    RowBin &b = H.bins[(size_t)bi];
+    if (b.n > TBIN) return false;   // cannot happen with the limits above; phase 2 holds exactly TBIN products
+    if (p_off + b.n > INT32_MAX) return false;
+    b.pstart = (int32_t)p_off;
+    p_off += b.n;
+    b.pt0 = (int32_t)n_pieces_total;                         // its pieces in ptab[]
+    b.gb0 = (int32_t)n_blocks_total;                         // its 64-group blocks in gblk[]
+    n_pieces_total += (int64_t)bin_pieces[(size_t)bi].size();
+    n_blocks_total += std::max<int64_t>(1, (b.n / 4 + 63) / 64);
+    for (Piece &pc : bin_pieces[(size_t)bi]) {
+      pc.pos = run_len[(size_t)pc.tile];
+      pc.ppos = run_plen[(size_t)pc.tile];
+      run_len[(size_t)pc.tile] += 4ll * pc.groups;
+      run_plen[(size_t)pc.tile] += pc.prods;
     }
-  H.p_len = p_off;
-  H.light_len = p_off;
-  {
-    int64_t pieces = 0;
-    for (const auto &v : bin_pieces) pieces += (int64_t)v.size();
-    H.tile_fill = (n_bins > 0) ? (double)pieces / ((double)n_bins * CT) : 1.0;
   }
-  std::vector<int64_t> slab_start((size_t)n_slabs + 1, 0), pdelta((size_t)n_slabs, 0);
+  H.p_len = p_off;
+  H.tile_fill = (n_bins > 0) ? (double)n_pieces_total / ((double)n_bins * CT) : 1.0;
   {
-    int64_t pos = 0;
-    for (int64_t sl = 0; sl < n_slabs; sl++) {
-      slab_start[(size_t)sl] = pos;
-      for (int t = 0; t < CT; t++) { run_start[(size_t)(sl * CT + t)] = pos; pos += run_len[(size_t)(sl * CT + t)]; }
-      pdelta[(size_t)sl] = (sl % H.ring) * H.slab_cap - slab_start[(size_t)sl];
-      if (H.ring >= n_slabs) pdelta[(size_t)sl] = 0;   // linear layout: P position == stream position
+    // every tile's light run starts on a multiple of 64 groups: phase 1's waves then cover whole obase[] blocks
+    int64_t pos = 0, ppos = 0;
+    for (int t = 0; t < CT; t++) {
+      run_start[(size_t)t] = pos; pos += (run_len[(size_t)t] + 255) & ~int64_t(255);
+      run_pstart[(size_t)t] = ppos; ppos += run_plen[(size_t)t];
     }
-    slab_start[(size_t)n_slabs] = pos;   // == light_len
+    H.light_len = pos;
   }
   // S2: heavy pieces; positions relative to the tile's heavy run
   H.heavy.resize((size_t)n_heavy);
@@ -536,7 +568,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   for (int t = 0; t < CT; t++) { heavy_start[t] = total; total += hrel[t]; }
   if (total > INT32_MAX - 8) return false;
   H.stream_len = total;
-  if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096)
+  if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096 + 256ll * CT)
     return false; // padding would cost more than 25 %: keep the stream plan
 
   // P3: value dictionary: <= VDICT distinct bit patterns => the stream carries one-byte codes, <= 16 => four-bit
@@ -596,11 +628,12 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     H.vdict.resize(VDICT, 0u);
   }
   else H.tval.assign((size_t)H.stream_len, 0u);
-  H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);
+  H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);   // padding: the identity column, value word / code 0, no fold flag
   H.gdest.assign((size_t)(H.stream_len - heavy_base) / HSTRIP + 1, 0u);   // partial slot of every heavy strip
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
   H.gblk.assign((size_t)(n_blocks_total + 1) * 4, 0u);
   H.ptab.assign((size_t)n_pieces_total + 1, 0);
+  std::atomic<bool> ok{true};
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
     const bool in_range = (uint32_t)c < (uint32_t)cols;
@@ -615,24 +648,71 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   parallel_items(n_bins, 8, NT, [&](int64_t bi, int th) {
     const RowBin &b = H.bins[(size_t)bi];
     Scratch &sc = scratch[(size_t)th];
-    int64_t off = b.pstart;
+    sort_bin(sc, b);
+    sc.row_next.assign((size_t)b.nr, 0);
+    int64_t off = b.pstart;      // next product of the bin (bin-major order: pslot)
     int32_t piece_k = 0;
     for (const Piece &pc : bin_pieces[(size_t)bi]) {
-      const int32_t padded = (pc.cnt + 3) & ~3;
-      const int64_t sl = slab_of_bin[(size_t)bi];
-      const int64_t spos = run_start[(size_t)(sl * CT + pc.tile)] + pc.pos;
+      const int64_t spos = run_start[(size_t)pc.tile] + pc.pos;      // stream position of the piece
+      const int64_t ppos = run_pstart[(size_t)pc.tile] + pc.ppos;    // P position of the piece (a multiple of 4)
       {
-        // where the piece lies in the P ring, as a group index relative to the piece's place in the bin: a group's
+        // where the piece lies in P, as a group index relative to the piece's place in the bin: a group's
         // P address is ptab[its piece] + its group index inside the bin.  gblk marks the group that starts a piece.
         const int64_t g_in_bin = (off - b.pstart) / 4;
-        H.ptab[(size_t)b.pt0 + (size_t)piece_k] = (int32_t)((spos + pdelta[(size_t)sl]) / 4 - g_in_bin);
+        H.ptab[(size_t)b.pt0 + (size_t)piece_k] = (int32_t)(ppos / 4 - g_in_bin);
         uint32_t *rec = &H.gblk[((size_t)b.gb0 + (size_t)(g_in_bin / 64)) * 4];
         rec[(g_in_bin % 64) / 32] |= 1u << (g_in_bin % 32);
-        piece_k++;
       }
-      sc.pos[(size_t)pc.tile] = spos;        // next free stream position of this (bin, tile) piece
-      sc.count[(size_t)pc.tile] = (int32_t)(off - spos);   // P position = stream position + this (fits: both < 2^31)
-      off += padded;
+      find_runs(sc, sc.start[(size_t)piece_k], sc.start[(size_t)piece_k + 1]);
+      // Lay the runs out group by group.  q: next stream position; o: next product of the piece.  A run of len entries
+      // at s_*[i..] gets fold flags on all but its last entry; free positions behind it in the same group are padding
+      // entries that either join it (flag on the entry in front) or -- the first `need` of them -- are padding products.
+      int64_t q = spos, o = 0;
+      const int64_t R = (int64_t)(sc.l4.size() + sc.l3.size() + sc.l2.size() + sc.l1.size());
+      int64_t need = (-R) & 3;
+      auto put_run = [&](int32_t i, int len) {
+        const int32_t rl = sc.s_row[(size_t)i];
+        for (int k = 0; k < len; k++) {
+          put_entry(q, sc.s_j[(size_t)i + k]);
+          if (k + 1 < len) H.tcol[(size_t)q] |= TCOL_FOLD;
+          q++;
+        }
+        const int64_t slot0 = light_off((int64_t)b.r0 + rl) - b.csr0;
+        H.pslot[(size_t)(off + o)] = (uint16_t)(slot0 + sc.row_next[(size_t)rl]++);
+        o++;
+      };
+      auto pad_to_group_end = [&]() {   // q is inside a group (or at its end): fill up with padding entries
+        while (q & 3) {
+          if (need > 0) { need--; o++; }               // a padding product of its own (slot stays TSLOT_PAD)
+          else H.tcol[(size_t)q - 1] |= TCOL_FOLD;     // joins the run in front of it
+          q++;
+        }
+      };
+      size_t s1 = 0;   // singles handed out so far
+      for (int32_t i : sc.l4) put_run(i, 4);
+      for (int32_t i : sc.l3) { put_run(i, 3); if (s1 < sc.l1.size()) put_run(sc.l1[s1++], 1); else pad_to_group_end(); }
+      for (size_t k = 0; k + 1 < sc.l2.size(); k += 2) { put_run(sc.l2[k], 2); put_run(sc.l2[k + 1], 2); }
+      if (sc.l2.size() & 1) {
+        put_run(sc.l2.back(), 2);
+        for (int k = 0; k < 2 && s1 < sc.l1.size(); k++) put_run(sc.l1[s1++], 1);
+        pad_to_group_end();
+      }
+      while (s1 < sc.l1.size()) {
+        put_run(sc.l1[s1++], 1);
+        if ((q & 3) == 0) continue;
+        if (s1 == sc.l1.size()) pad_to_group_end();
+      }
+      if (need > 0) {   // one more group: `need` padding products (the last one made of the remaining entries)
+        for (int k = 0; k < 4; k++) {
+          if (need > 0) { need--; o++; }
+          else H.tcol[(size_t)q - 1] |= TCOL_FOLD;
+          q++;
+        }
+      }
+      // (the layout above must agree with pack_piece(): sizes were fixed from it)
+      if (q - spos != 4ll * pc.groups || o != pc.prods) ok = false;
+      off += pc.prods;
+      piece_k++;
     }
     {
       const int64_t nblk = std::max<int64_t>(1, (b.n / 4 + 63) / 64);
@@ -643,17 +723,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         before += (uint32_t)(__builtin_popcount(rec[0]) + __builtin_popcount(rec[1]));
       }
     }
-    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
-      if (is_heavy(r)) continue;
-      const int64_t slot0 = light_off(r) - b.csr0;
-      for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
-        const int t = tile_of(ci[j]);
-        const int64_t pos = sc.pos[(size_t)t]++;
-        put_entry(pos, j);
-        H.pslot[(size_t)(pos + sc.count[(size_t)t])] = (uint16_t)(slot0 + (j - rp[r]));
-      }
-    }
-    for (const Piece &pc : bin_pieces[(size_t)bi]) sc.count[(size_t)pc.tile] = 0;   // scratch back to all-zero
   });
   parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
     const LongRow &lr = H.heavy[(size_t)hi];
@@ -676,9 +745,25 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int32_t j = rp[r]; j < rp[r + 1]; j++)
       put_entry(sc.pos[(size_t)tile_of(ci[j])]++, j);
   });
-  // 4. phase-1 work items: <= TCHUNK entries of one (slab, tile) run, or of one tile's heavy run
+  // P6: obase[block] = P position of the first product of the block's 64 stream groups (a group yields one product
+  // per entry WITHOUT a fold flag).  Read back from the flags just written, so the two cannot disagree; a tile's
+  // run ends in padding groups (run starts are multiples of 64 groups) whose products nobody reads.
+  std::vector<int64_t> ob0((size_t)CT + 1, 0);
+  for (int t = 0; t < CT; t++) ob0[(size_t)t + 1] = ob0[(size_t)t] + (((run_len[(size_t)t] + 255) & ~int64_t(255)) / 256);
+  H.obase.assign((size_t)ob0[(size_t)CT] + 1, 0u);
+  parallel_items(CT, 1, NT, [&](int64_t t, int) {
+    int64_t pp = run_pstart[(size_t)t];
+    const int64_t s0 = run_start[(size_t)t], s1 = s0 + run_len[(size_t)t];
+    for (int64_t q = s0; q < s1; q++) {
+      if (((q - s0) & 255) == 0) H.obase[(size_t)(ob0[(size_t)t] + (q - s0) / 256)] = (uint32_t)pp;
+      if (!(H.tcol[(size_t)q] & TCOL_FOLD)) pp++;
+    }
+    if (pp != run_pstart[(size_t)t] + run_plen[(size_t)t]) ok = false;
+  });
+  if (!ok) return false;
+  // 4. phase-1 work items: <= chunk entries of one tile's light run, or of one tile's heavy run
   //    (cuts are multiples of 64 groups from the run start, so wave boundaries are the ones assumed
-  //    above).  Order: slab-major; inside a slab workgroups are dealt round-robin over the 8 XCDs
+  //    above).  Workgroups are dealt round-robin over the 8 XCDs
   //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
   //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
   //    of all of it (speed only; correctness does not depend on placement).
@@ -689,10 +774,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // (-7 % on a 1/8 shard against 32 K).  opt.chunk > 0 overrides.
   auto items_at = [&](int64_t c) {
     int64_t n = 0;
-    for (int t = 0; t < CT; t++) {
-      for (int64_t sl = 0; sl < n_slabs; sl++) n += (run_len[(size_t)(sl * CT + t)] + c - 1) / c;
-      n += (hrel[(size_t)t] + c - 1) / c;
-    }
+    for (int t = 0; t < CT; t++) n += (run_len[(size_t)t] + c - 1) / c + (hrel[(size_t)t] + c - 1) / c;
     return n;
   };
   int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(65536) >= 6ll * std::max(n_cus, 1) ? 65536 : 49152);
@@ -707,10 +789,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   std::vector<std::vector<std::pair<int64_t, int>>> tile_segs((size_t)CT);
   {
     std::vector<int64_t> weight((size_t)CT, 0);
-    for (int t = 0; t < CT; t++) {
-      weight[(size_t)t] = hrel[(size_t)t];
-      for (int64_t sl = 0; sl < n_slabs; sl++) weight[(size_t)t] += run_len[(size_t)(sl * CT + t)];
-    }
+    for (int t = 0; t < CT; t++) weight[(size_t)t] = hrel[(size_t)t] + run_len[(size_t)t];
     const int64_t fair = std::max<int64_t>(chunk, H.stream_len / 8);
     bool uniform = true;   // no tile far above the mean: keep the plain tile % 8 order
     for (int t = 0; t < CT; t++) uniform = uniform && weight[(size_t)t] * CT <= 2 * H.stream_len + 2 * chunk * CT;
@@ -739,29 +818,28 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       if (before < sg.first) return sg.second;
     return tile_segs[(size_t)t].empty() ? (t & 7) : tile_segs[(size_t)t].back().second;
   };
-  // entries of tile t that precede (slab sl, offset 0) / the tile's heavy run in the tile's own order: light runs, then heavy
-  auto tile_before = [&](int t, int64_t sl) -> int64_t {
-    int64_t n = 0;
-    for (int64_t k = 0; k < (sl < 0 ? n_slabs : sl); k++) n += run_len[(size_t)(k * CT + t)];
-    return n;
-  };
-  std::vector<TileChunk> queue[8];
-  H.need.assign((size_t)n_slabs * 2, 0);
   // cut one run into chunks
-  auto cut_run = [&](int t, int64_t start, int64_t len, int32_t slab, std::vector<TileChunk> (&per_xcd)[8]) {
-    const bool heavy = slab < 0;
+  std::vector<TileChunk> per_xcd[8];
+  auto cut_run = [&](int t, int64_t start, int64_t len, bool heavy) {
     // equal cuts: a run of 56 K entries becomes 2 x 28 K, not 32 K + 24 K (the launch ends with its slowest workgroup)
     const int64_t pieces = (len + chunk - 1) / chunk;
     const int64_t cut = pieces > 0 ? std::min<int64_t>(chunk, ((len + pieces - 1) / pieces + 64 * HSTRIP - 1) & ~int64_t(64 * HSTRIP - 1)) : chunk;
     for (int64_t s0 = start; s0 < start + len; s0 += cut) {
       const int64_t e0 = std::min<int64_t>(s0 + cut, start + len);
+      // light chunks: ob0 = the chunk's first block of obase[] (cuts are multiples of 256 entries from the run start)
       TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
-                   (int32_t)(heavy ? H.heavy_base : pdelta[(size_t)slab]), slab, 0, 0};
-      per_xcd[home_of(t, tile_before(t, slab) + (s0 - start))].push_back(ch);
+                   (int32_t)(heavy ? H.heavy_base : 0), (int32_t)(heavy ? 0 : ob0[(size_t)t] + (s0 - start) / 256), 0, 0};
+      per_xcd[home_of(t, (heavy ? run_len[(size_t)t] : 0) + (s0 - start))].push_back(ch);
     }
   };
-  // append per-XCD lists to H.chunks so that position p holds a chunk of XCD p % 8 (empty fillers where a list is short)
-  auto interleave = [&](std::vector<TileChunk> (&per_xcd)[8]) {
+  // ONE phase-1 launch, tile by tile -- a tile's light chunks, then its heavy chunks -- so that memory-bound
+  // light chunks and the ALU-heavier heavy chunks are in flight together.
+  for (int t = 0; t < CT; t++) {
+    cut_run(t, run_start[(size_t)t], run_len[(size_t)t], false);
+    cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], true);
+  }
+  // per-XCD lists interleaved so that position p holds a chunk of XCD p % 8 (empty fillers where a list is short)
+  {
     size_t longest = 0;
     for (auto &v : per_xcd) longest = std::max(longest, v.size());
     if (!xcd_order)
@@ -770,60 +848,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       for (size_t i = 0; i < longest; i++)
         for (int c = 0; c < 8; c++)
           H.chunks.push_back(i < per_xcd[c].size() ? per_xcd[c][i] : TileChunk{0, 0, 0, 0, 0, 0, 0, 0});   // empty filler
-  };
-  if (H.ring >= n_slabs) {
-    // No slot of P is reused: ONE phase-1 launch, tile by tile -- a tile's light chunks, then its heavy
-    // chunks -- so that memory-bound light chunks and the ALU-heavier heavy chunks are in flight together.
-    std::vector<TileChunk> per_xcd[8];
-    for (int t = 0; t < CT; t++) {
-      for (int64_t sl = 0; sl < n_slabs; sl++)
-        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, per_xcd);
-      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, per_xcd);
-    }
-    interleave(per_xcd);
-    H.slab_chunk0.assign((size_t)n_slabs, 0);
-    H.slab_chunk0.push_back((int32_t)H.chunks.size());   // [0, all) = everything ...
-    H.slab_chunk0.push_back((int32_t)H.chunks.size());   // ... and no separate heavy range
-  } else {
-    // P slots are reused: one phase-1 launch per slab (slab-major lists), the heavy chunks in a list of their own
-    for (int64_t sl = 0; sl < n_slabs; sl++) {
-      std::vector<TileChunk> per_xcd[8];
-      H.slab_chunk0.push_back((int32_t)H.chunks.size());
-      for (int t = 0; t < CT; t++)
-        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, per_xcd);
-      interleave(per_xcd);
-    }
-    std::vector<TileChunk> per_xcd[8];
-    H.slab_chunk0.push_back((int32_t)H.chunks.size());
-    for (int t = 0; t < CT; t++)
-      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, per_xcd);
-    interleave(per_xcd);
-    H.slab_chunk0.push_back((int32_t)H.chunks.size());
   }
-  // the fused launch's queues: light chunks slab-major per XCD (no fillers), heavy chunks, per-slab counts
-  {
-    std::vector<TileChunk> tmp[8];
-    for (int64_t sl = 0; sl < n_slabs; sl++) {
-      for (auto &v : tmp) v.clear();
-      for (int t = 0; t < CT; t++)
-        cut_run(t, run_start[(size_t)(sl * CT + t)], run_len[(size_t)(sl * CT + t)], (int32_t)sl, tmp);
-      for (int q = 0; q < 8; q++) {
-        queue[q].insert(queue[q].end(), tmp[q].begin(), tmp[q].end());
-        H.need[(size_t)sl * 2] += (int32_t)tmp[q].size();
-      }
-    }
-    for (auto &v : tmp) v.clear();
-    for (int t = 0; t < CT; t++)
-      cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], -1, tmp);
-    for (int q = 0; q < 8; q++) H.hchunks.insert(H.hchunks.end(), tmp[q].begin(), tmp[q].end());
-  }
-  for (int q = 0; q < 8; q++) {
-    H.lq0[q] = (int32_t)H.qchunks.size();
-    H.qchunks.insert(H.qchunks.end(), queue[q].begin(), queue[q].end());
-  }
-  H.lq0[8] = (int32_t)H.qchunks.size();
-  for (int64_t sl = 0; sl < n_slabs; sl++)
-    H.need[(size_t)sl * 2 + 1] = H.slab_bin0[(size_t)sl + 1] - H.slab_bin0[(size_t)sl];
   return true;
 }
 
@@ -860,11 +885,19 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
   (void)hipFree(xv.d);
   (void)hipFree(ov.d);
   m->plan = (ok && ms[PLAN_STREAM] < 0.9f * ms[PLAN_TILED]) ? PLAN_STREAM : PLAN_TILED;
-  if (m->plan == PLAN_STREAM) {   // the tiled layout is of no further use
+  // the layout of the plan that lost is of no further use
+  if (m->plan == PLAN_STREAM) {
+    m->tiled_bytes = 0;
     for (void **p : {(void **)&m->d_bins, (void **)&m->d_chunks, (void **)&m->d_tval, (void **)&m->d_tcol, (void **)&m->d_gdest,
                      (void **)&m->d_pslot, (void **)&m->d_gblk, (void **)&m->d_ptab, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
-                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_qchunks, (void **)&m->d_hchunks,
-                     (void **)&m->d_lq0, (void **)&m->d_need, (void **)&m->d_ctl}) {
+                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_obase}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+  } else {
+    m->stream_bytes = 0;
+    for (void **p : {(void **)&m->d_row_ptr, (void **)&m->d_col, (void **)&m->d_val, (void **)&m->d_blk_row, (void **)&m->d_segs,
+                     (void **)&m->d_long, (void **)&m->d_partial}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -888,9 +921,7 @@ void sh_plan_options_default(sh_plan_options *o) {
   o->heavy_per_tile = 8;
   o->chunk = 0;   // auto (see build_tiled_plan)
   o->xcd_order = 1;
-  o->ring = 3;
-  o->n2 = 16;
-  o->slab_mb = 0;   // one slab
+  o->fold = 1;
 }
 
 void sh_plan_options_from_env(sh_plan_options *o) {
@@ -904,10 +935,7 @@ void sh_plan_options_from_env(sh_plan_options *o) {
   num("SH_HEAVY_PER_TILE", o->heavy_per_tile);
   num("SH_CHUNK", o->chunk);
   if (const char *v = getenv("SH_XCD_ORDER")) o->xcd_order = v[0] != '0';
-  if (const char *v = getenv("SH_FUSED")) o->fused = v[0] == '1';
-  num("SH_RING", o->ring);
-  num("SH_N2", o->n2);
-  if (const char *v = getenv("SH_SLAB_MB")) o->slab_mb = atof(v);
+  if (const char *v = getenv("SH_FOLD")) o->fold = v[0] != '0';
 }
 
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
@@ -935,22 +963,11 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     return fail(e, SH_ENOMEM, "out of host memory");
   m->rows = rows; m->cols = cols; m->nnz = nnz;
 
-  std::vector<int32_t> pairs;
-  std::vector<LongSeg> segs;
-  std::vector<LongRow> longs;
   for (int64_t r = 0; r < rows; r++)
     if (row_ptr[r + 1] < row_ptr[r]) {
       delete m;
       return fail(e, SH_ESHAPE, "sh_csr_upload: row_ptr not monotone at row %lld", (long long)r);
     }
-  build_schedule(rows, row_ptr, pairs, segs, longs);
-  // compact (r0,r1) pairs into a boundary list usable as blk_row[b], blk_row[b+1]:
-  // blocks are consecutive except across long rows, so store both ends.
-  m->n_stream = (int32_t)(pairs.size() / 2);
-  m->n_segs = (int32_t)segs.size();
-  m->n_long = (int32_t)longs.size();
-
-  const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;
   auto cleanup = [&](int rc) { sh_csr_free(e, m); return rc; };
 #define HIP_TRY_M(call)                                                         \
   do {                                                                          \
@@ -959,116 +976,92 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       return cleanup(fail(e, _r == hipErrorOutOfMemory ? SH_ENOMEM : SH_EHIP,   \
                           "%s failed: %s", #call, hipGetErrorString(_r)));      \
   } while (0)
-  HIP_TRY_M(hipMalloc((void **)&m->d_row_ptr, (rows + 1) * 4));
-  HIP_TRY_M(hipMalloc((void **)&m->d_col, padded * 4));
-  HIP_TRY_M(hipMalloc((void **)&m->d_val, padded * 4));
-  HIP_TRY_M(hipMemsetAsync(m->d_col + (padded - 8 > 0 ? padded - 8 : 0), 0xFF, (padded >= 8 ? 8 : padded) * 4, e->stream));
-  HIP_TRY_M(hipMemsetAsync(m->d_val + (padded - 8 > 0 ? padded - 8 : 0), 0, (padded >= 8 ? 8 : padded) * 4, e->stream));
-  HIP_TRY_M(hipMemcpyAsync(m->d_row_ptr, row_ptr, (rows + 1) * 4, hipMemcpyHostToDevice, e->stream));
-  if (nnz > 0) {
-    HIP_TRY_M(hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMemcpyAsync(m->d_val, val, nnz * 4, hipMemcpyHostToDevice, e->stream));
-  }
-  // The kernel reads blk_row[b] and blk_row[b+1]; with long rows in between the
-  // blocks are not contiguous, so upload the pair list and index it as 2*b.
-  HIP_TRY_M(hipMalloc((void **)&m->d_blk_row, (pairs.size() + 2) * 4));
-  if (!pairs.empty())
-    HIP_TRY_M(hipMemcpyAsync(m->d_blk_row, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, e->stream));
-  if (m->n_segs) {
-    HIP_TRY_M(hipMalloc((void **)&m->d_segs, segs.size() * sizeof(LongSeg)));
-    HIP_TRY_M(hipMemcpyAsync(m->d_segs, segs.data(), segs.size() * sizeof(LongSeg), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_long, longs.size() * sizeof(LongRow)));
-    HIP_TRY_M(hipMemcpyAsync(m->d_long, longs.data(), longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_partial, segs.size() * 4));
-  }
+  // device array of `bytes` (+ slack for the kernels' wide loads), filled from `host` when given; counted in the footprint
+#define DEV_ARRAY(ptr, host, bytes, slack)                                                                    \
+  do {                                                                                                        \
+    HIP_TRY_M(hipMalloc((void **)&(ptr), (size_t)(bytes) + (slack)));                                         \
+    *acct += (size_t)(bytes) + (slack);                                                                       \
+    if ((host) != nullptr && (bytes) > 0)                                                                     \
+      HIP_TRY_M(hipMemcpyAsync((ptr), (host), (size_t)(bytes), hipMemcpyHostToDevice, e->stream));            \
+  } while (0)
+
+  // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
+  // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
   TiledHost th;
-  m->plan = PLAN_STREAM;
-  if (choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
-      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th)) {
-    m->plan = PLAN_TILED;
+  const bool tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
+                     build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th);
+  // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
+  // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
+  const bool tune = tiled && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5;
+  m->plan = tiled ? PLAN_TILED : PLAN_STREAM;
+  size_t *acct = &m->stream_bytes;
+  if (!tiled || tune) {
+    std::vector<int32_t> pairs;
+    std::vector<LongSeg> segs;
+    std::vector<LongRow> longs;
+    build_schedule(rows, row_ptr, pairs, segs, longs);
+    m->n_stream = (int32_t)(pairs.size() / 2);
+    m->n_segs = (int32_t)segs.size();
+    m->n_long = (int32_t)longs.size();
+    const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;   // the tail is padded so that 16-byte loads at the end stay in bounds
+    DEV_ARRAY(m->d_row_ptr, row_ptr, (rows + 1) * 4, 0);
+    DEV_ARRAY(m->d_col, (const int32_t *)nullptr, padded * 4, 0);
+    DEV_ARRAY(m->d_val, (const uint32_t *)nullptr, padded * 4, 0);
+    HIP_TRY_M(hipMemsetAsync(m->d_col + (padded - 8 > 0 ? padded - 8 : 0), 0xFF, (padded >= 8 ? 8 : padded) * 4, e->stream));
+    HIP_TRY_M(hipMemsetAsync(m->d_val + (padded - 8 > 0 ? padded - 8 : 0), 0, (padded >= 8 ? 8 : padded) * 4, e->stream));
+    if (nnz > 0) {
+      HIP_TRY_M(hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY_M(hipMemcpyAsync(m->d_val, val, nnz * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    // The kernel reads blk_row[b] and blk_row[b+1]; with long rows in between the
+    // blocks are not contiguous, so upload the pair list and index it as 2*b.
+    DEV_ARRAY(m->d_blk_row, pairs.data(), pairs.size() * 4, 8);
+    if (m->n_segs) {
+      DEV_ARRAY(m->d_segs, segs.data(), segs.size() * sizeof(LongSeg), 0);
+      DEV_ARRAY(m->d_long, longs.data(), longs.size() * sizeof(LongRow), 0);
+      DEV_ARRAY(m->d_partial, (const uint32_t *)nullptr, segs.size() * 4, 0);
+    }
+    HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
+  }
+  acct = &m->tiled_bytes;
+  if (tiled) {
     m->n_bins = (int32_t)th.bins.size();
     m->n_chunks = (int32_t)th.chunks.size();
     m->n_tlong = (int32_t)th.heavy.size();
     m->light_len = th.light_len;
     m->stream_len = th.stream_len;
     m->p_len = th.p_len;
-    m->slab_bin0 = th.slab_bin0;
-    m->slab_chunk0 = th.slab_chunk0;
-    m->slab_cap = th.slab_cap;
-    m->ring = th.ring;
-    const int64_t n_slabs = (int64_t)th.slab_bin0.size() - 1;
-    m->p_alloc = (th.ring >= n_slabs) ? th.light_len : (int64_t)th.ring * th.slab_cap;
-    HIP_TRY_M(hipMalloc((void **)&m->d_bins, th.bins.size() * sizeof(RowBin)));
-    HIP_TRY_M(hipMemcpyAsync(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_chunks, th.chunks.size() * sizeof(TileChunk)));
-    HIP_TRY_M(hipMemcpyAsync(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
+    m->light_entries = th.light_entries;
+    m->fold = opt.fold != 0;
+    DEV_ARRAY(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), 0);
+    DEV_ARRAY(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), 0);
     if (!th.vdict.empty()) {
       m->n_vdict = (int)th.vdict.size();
       m->n_vdict_used = th.vdict_used;
       m->code_bits = th.code_bits;
-      HIP_TRY_M(hipMalloc((void **)&m->d_tcode, th.tcode.size() + 64));
-      HIP_TRY_M(hipMemcpyAsync(m->d_tcode, th.tcode.data(), th.tcode.size(), hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_vdict, th.vdict.size() * 4));
-      HIP_TRY_M(hipMemcpyAsync(m->d_vdict, th.vdict.data(), th.vdict.size() * 4, hipMemcpyHostToDevice, e->stream));
+      DEV_ARRAY(m->d_tcode, th.tcode.data(), th.tcode.size(), 64);
+      DEV_ARRAY(m->d_vdict, th.vdict.data(), th.vdict.size() * 4, 0);
     } else {
-      HIP_TRY_M(hipMalloc((void **)&m->d_tval, th.tval.size() * 4 + 16));
-      HIP_TRY_M(hipMemcpyAsync(m->d_tval, th.tval.data(), th.tval.size() * 4, hipMemcpyHostToDevice, e->stream));
+      DEV_ARRAY(m->d_tval, th.tval.data(), th.tval.size() * 4, 16);
     }
-    HIP_TRY_M(hipMalloc((void **)&m->d_tcol, th.tcol.size() * 2 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_gdest, th.gdest.size() * 4 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_gblk, th.gblk.size() * 4 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_gblk, th.gblk.data(), th.gblk.size() * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_ptab, th.ptab.size() * 4 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_ptab, th.ptab.data(), th.ptab.size() * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_pslot, th.pslot.size() * 2 + 16));
-    HIP_TRY_M(hipMemcpyAsync(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY_M(hipMalloc((void **)&m->d_P, (size_t)std::max<int64_t>(m->p_alloc, 4) * 4 + 16));
-    HIP_TRY_M(hipMalloc((void **)&m->d_lrp, th.lrp.size() * 4));
-    HIP_TRY_M(hipMemcpyAsync(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, hipMemcpyHostToDevice, e->stream));
-    {
-      // the fused launch needs every workgroup resident at once: one per CU (LDS), grid = CU count
-      // Opt-in (SH_FUSED=1): measured slower than two launches on MI355X -- both roles are bound by what one CU
-      // keeps in flight, not by HBM, so running them side by side on half the CUs each gains nothing
-      // ("slab-pipelined fused launch"; profiles/r02_fused_*).
-      m->fused = opt.fused == 1 && e->n_cus >= 16;
-      m->n2 = std::max(1, std::min(opt.n2, e->n_cus / 8 - 1));
-      // A phase-2 worker waits for its NEXT bin's slab while its current bin is unfinished.  That is only
-      // free of cycles if the next bin (8 * n2 bins further) is at most one slab ahead and the slab after
-      // the current one does not need the current one's ring slot: every slab but the last must hold
-      // >= 8 * n2 bins, and the ring >= 2 slots (kernels.hip.h, tiled_phase2_run).
-      int32_t min_bins = INT32_MAX;
-      for (int64_t sl = 0; sl + 1 < n_slabs; sl++)
-        min_bins = std::min(min_bins, th.slab_bin0[(size_t)sl + 1] - th.slab_bin0[(size_t)sl]);
-      m->n2 = std::min(m->n2, min_bins / 8);
-      if (m->n2 < 1 || (n_slabs > 1 && th.ring < 2)) m->fused = false;
-      m->n_hchunks = (int32_t)th.hchunks.size();
-      m->ctl_words = CTL_GATES + GATE_WORDS * (1 + 2 * (int32_t)n_slabs);
-      HIP_TRY_M(hipMalloc((void **)&m->d_qchunks, (th.qchunks.size() + 1) * sizeof(TileChunk)));
-      HIP_TRY_M(hipMemcpyAsync(m->d_qchunks, th.qchunks.data(), th.qchunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_hchunks, (th.hchunks.size() + 1) * sizeof(TileChunk)));
-      HIP_TRY_M(hipMemcpyAsync(m->d_hchunks, th.hchunks.data(), th.hchunks.size() * sizeof(TileChunk), hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_lq0, sizeof th.lq0));
-      HIP_TRY_M(hipMemcpyAsync(m->d_lq0, th.lq0, sizeof th.lq0, hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_need, (th.need.size() + 2) * 4));
-      HIP_TRY_M(hipMemcpyAsync(m->d_need, th.need.data(), th.need.size() * 4, hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_ctl, (size_t)m->ctl_words * 4));
-    }
+    DEV_ARRAY(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, 16);
+    DEV_ARRAY(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, 16);
+    DEV_ARRAY(m->d_gblk, th.gblk.data(), th.gblk.size() * 4, 16);
+    DEV_ARRAY(m->d_ptab, th.ptab.data(), th.ptab.size() * 4, 16);
+    DEV_ARRAY(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, 16);
+    DEV_ARRAY(m->d_obase, th.obase.data(), th.obase.size() * 4, 16);
+    DEV_ARRAY(m->d_P, (const uint32_t *)nullptr, (size_t)std::max<int64_t>(m->p_len, 4) * 4, 16);
+    DEV_ARRAY(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, 0);
     if (m->n_tlong) {
-      HIP_TRY_M(hipMalloc((void **)&m->d_tlong, th.heavy.size() * sizeof(LongRow)));
-      HIP_TRY_M(hipMemcpyAsync(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), hipMemcpyHostToDevice, e->stream));
-      HIP_TRY_M(hipMalloc((void **)&m->d_tpartial, (size_t)th.n_partials * 4 + 16));
+      DEV_ARRAY(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), 0);
+      DEV_ARRAY(m->d_tpartial, (const uint32_t *)nullptr, (size_t)th.n_partials * 4, 16);
     }
+    HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
   }
-  HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
+#undef DEV_ARRAY
 #undef HIP_TRY_M
-  {
-    // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
-    // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
-    if (m->plan == PLAN_TILED && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5)
-      autotune_plan(e, m);
-  }
+  if (tune)
+    autotune_plan(e, m);   // frees the arrays of the plan that lost
   *out = m;
   return SH_OK;
 }
@@ -1089,8 +1082,7 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
                   (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
-                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_qchunks, (void *)m->d_hchunks, (void *)m->d_lq0,
-                  (void *)m->d_need, (void *)m->d_ctl})
+                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase})
     if (p) (void)hipFree(p);
   delete m;
   return SH_OK;
@@ -1121,7 +1113,8 @@ int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
                           ? (m->n_vdict ? 2ull : 6ull) * m->stream_len + (m->n_vdict ? (uint64_t)m->stream_len * m->code_bits / 8 : 0ull) + (uint64_t)(m->stream_len - m->light_len) / 4 /* gdest: 4 B per 16-entry strip */ +
-                                4ull * m->light_len /* P written */ + 6ull * m->light_len + m->light_len / 6 /* phase 2: P, slot; piece tables ~0.14 B per product */ +
+                                (uint64_t)m->light_len / 64 /* obase: 4 B per 64 groups */ +
+                                4ull * m->p_len /* P written */ + 6ull * m->p_len + m->p_len / 6 /* phase 2: P, slot; piece tables ~0.14 B per product */ +
                                 vec /* x once: a tile is re-staged per phase-1 workgroup, but out of its XCD's L2 */
                           : 8ull * m->nnz + vec;
   }
@@ -1135,13 +1128,9 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     char vals[32];
     if (m->n_vdict) snprintf(vals, sizeof vals, "dict%d(%d)", m->code_bits, m->n_vdict_used);
     else snprintf(vals, sizeof vals, "raw");
-    char slabs[64];
-    const int n_slabs = (int)m->slab_bin0.size() - 1;
-    if (m->ring >= n_slabs) snprintf(slabs, sizeof slabs, "slabs=%d", n_slabs);
-    else snprintf(slabs, sizeof slabs, "slabs=%d ring=%dx%.2fMB", n_slabs, m->ring, m->slab_cap * 4 / 1048576.0);
-    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM pieces=table %s%s", vals,
+    snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM products=%.1fM%s", vals,
              (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
-             m->light_len / 1e6, slabs, m->fused ? " fused" : "");
+             m->light_entries / 1e6, m->p_len / 1e6, m->fold ? " folded" : "");
   } else {
     snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);
   }
@@ -1149,6 +1138,17 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     const size_t len = strlen(buf);
     snprintf(buf + len, buflen - len, " tuned(stream=%.3fms,tiled=%.3fms)", m->tuned_ms[0], m->tuned_ms[1]);
   }
+  {
+    const size_t len = strlen(buf);
+    snprintf(buf + len, buflen - len, " device=%.3fGB", (double)(m->stream_bytes + m->tiled_bytes) / 1e9);
+  }
+  return SH_OK;
+}
+
+int sh_csr_footprint(const sh_csr *m, uint64_t *device_bytes) {
+  if (!m || !device_bytes)
+    return SH_EINVAL;
+  *device_bytes = (uint64_t)(m->stream_bytes + m->tiled_bytes);
   return SH_OK;
 }
 
@@ -1216,7 +1216,7 @@ int sh_vec_download(sh_engine *e, const sh_vec *v, void *host, int64_t n) {
     return fail(e, SH_ESHAPE, "sh_vec_download: %lld elements from a vector of %lld", (long long)n, (long long)v->n);
   HIP_TRY(e, hipMemcpyAsync(host, v->d, n * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return check_gave_up(e);
+  return SH_OK;
 }
 
 int sh_vec_fill(sh_engine *e, sh_vec *v, uint32_t pattern32) {
@@ -1257,105 +1257,38 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
   if (A->plan == PLAN_TILED) {
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
-    auto phase1 = [&](int32_t c0, int32_t c1) {
-      if (c1 <= c0) return;
-      const TileChunk *ch = A->d_chunks + c0;
-      if (A->n_vdict && A->code_bits == 4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
-                           ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
-      else if (A->n_vdict)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
-                           ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), dim3(c1 - c0), dim3(TBS), 0, e->stream,
-                           ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest,
-                           (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, (uint32_t)(A->p_alloc * 4), A->d_tpartial, st.gate);
-    };
-    const int n_slabs = (int)A->slab_bin0.size() - 1;
-    if (A->fused) {
-      // one persistent launch: phase-1 and phase-2 workers side by side, slab hand-offs through counters
-      FusedDev D{};
-      D.qchunks = A->d_qchunks; D.lq0 = A->d_lq0; D.hchunks = A->d_hchunks; D.n_hchunks = A->n_hchunks;
-      D.cols = (int32_t)A->cols;
-      D.tval = A->n_vdict ? (const void *)A->d_tcode : (const void *)A->d_tval;
-      D.vdict = A->d_vdict; D.tcol = A->d_tcol; D.gdest = A->d_gdest; D.x = (const uint32_t *)x->d;
-      D.P = A->d_P; D.p_bytes = (uint32_t)(A->p_alloc * 4); D.last_group = (int32_t)(A->p_alloc / 4 - 1);
-      D.partial = A->d_tpartial; D.bins = A->d_bins; D.lrp = A->d_lrp; D.pslot = A->d_pslot; D.gblk = (const uint4 *)A->d_gblk; D.ptab = A->d_ptab;
-      D.heavy_rows = A->d_tlong; D.need = A->d_need; D.ctl = A->d_ctl; D.err = (uint32_t *)(e->h_flag + 8);
 #ifdef SH_STATS
-      static uint64_t *g_stats = nullptr;
-      if (!g_stats) (void)hipMalloc((void **)&g_stats, 8192 * 8);
-      D.stats = g_stats;
-      D.dbg = getenv("SH_DBG") ? atoi(getenv("SH_DBG")) : 0;
-#endif
-      D.n_bins = A->n_bins; D.n_heavy = A->n_tlong; D.n_slabs = n_slabs; D.ring = A->ring; D.n2 = A->n2;
-      HIP_TRY(e, hipMemsetAsync(A->d_ctl, 0, (size_t)A->ctl_words * 4, e->stream));
-      const dim3 grid((unsigned)(e->n_cus & ~7));
-      if (A->n_vdict && A->code_bits == 4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 2>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
-                           use_y ? 1 : 0, (uint32_t *)out->d, st);
-      else if (A->n_vdict)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 1>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
-                           use_y ? 1 : 0, (uint32_t *)out->d, st);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_fused<SR, 0>), grid, dim3(P2S_BS), 0, e->stream, D, yp, alpha, beta,
-                           use_y ? 1 : 0, (uint32_t *)out->d, st);
-      HIP_TRY(e, hipGetLastError());
-#ifdef SH_STATS
-      if (getenv("SH_STATS_DUMP")) {   // development builds only: per-role timeline of this launch (100 MHz ticks -> us)
-        std::vector<uint64_t> hs((size_t)grid.x * 8), sl((size_t)n_slabs * 2);
-        (void)hipStreamSynchronize(e->stream);
-        (void)hipMemcpy(hs.data(), g_stats, hs.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(sl.data(), g_stats + 4096, sl.size() * 8, hipMemcpyDeviceToHost);
-        uint64_t t0 = ~0ull;
-        for (unsigned w = 0; w < grid.x; w++) t0 = std::min(t0, hs[w * 8 + 2]);
-        fprintf(stderr, "[stats] slab produced / consumed at (us):");
-        for (int i = 0; i < n_slabs; i++) fprintf(stderr, " %d: %.0f/%.0f", i, (sl[2 * i] - t0) / 100.0, (sl[2 * i + 1] - t0) / 100.0);
-        fprintf(stderr, "\n");
-        for (int role = 0; role < 2; role++) {
-          double n = 0, items = 0, main_end = 0, heavy_end = 0, end = 0, wait = 0, heavy = 0, start = 0, max_end = 0, max_main = 0;
-          for (unsigned w = 0; w < grid.x; w++) {
-            const uint64_t *S = &hs[w * 8];
-            if ((int)S[0] != role) continue;
-            n++; items += S[1]; start += (S[2] - t0) / 100.0; main_end += (S[3] - t0) / 100.0; heavy_end += (S[4] - t0) / 100.0;
-            end += (S[7] - t0) / 100.0; wait += S[5] / 100.0; heavy += S[6];
-            max_end = std::max(max_end, (S[7] - t0) / 100.0); max_main = std::max(max_main, (S[3] - t0) / 100.0);
-          }
-          if (n > 0)
-            fprintf(stderr, "[stats] role %s: %3.0f WGs, items/WG %.1f, start %.1f us, main loop ends avg %.1f max %.1f, heavy queue ends %.1f (%.1f chunks/WG), "
-                    "kernel end avg %.1f max %.1f, waiting %.1f us/WG\n", role ? "phase2" : "phase1", n, items / n, start / n, main_end / n, max_main,
-                    heavy_end / n, heavy / n, end / n, max_end, wait / n);
-        }
-      }
-#endif
-      return SH_OK;
-    }
-#ifdef SH_STATS
-    static uint64_t *p1_stats = nullptr;
+    static uint64_t *p1_stats = nullptr;   // tools builds: per-chunk timeline of phase 1
     if (getenv("SH_STATS_DUMP")) {
       if (!p1_stats) (void)hipMalloc((void **)&p1_stats, (size_t)1 << 22);
       (void)hipMemsetAsync(p1_stats, 0, (size_t)1 << 22, e->stream);
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_p1_stats), &p1_stats, sizeof p1_stats, 0, hipMemcpyHostToDevice, e->stream);
     }
 #endif
-    // separate launches (SH_FUSED=0).  The heavy rows' (row, tile) sums first: they only feed the partials
-    phase1(A->slab_chunk0[(size_t)n_slabs], A->slab_chunk0[(size_t)n_slabs + 1]);
-    HIP_TRY(e, hipGetLastError());
-    // With a ring, slab by slab: phase 2 of a slab has to finish before a later slab may overwrite its
-    // slot.  Without slot reuse (ring >= slabs) one phase-1 and one phase-2 launch cover everything.  The
-    // last phase-2 launch's reducer waves also add up the heavy rows' partials.
-    const int step = A->ring >= n_slabs ? std::max(n_slabs, 1) : 1;
-    for (int sl = 0; sl < n_slabs; sl += step) {
-      const int sl1 = std::min(n_slabs, sl + step);
-      phase1(A->slab_chunk0[(size_t)sl], A->slab_chunk0[(size_t)sl1]);
-      HIP_TRY(e, hipGetLastError());
-      const int32_t b0 = A->slab_bin0[(size_t)sl], nb = A->slab_bin0[(size_t)sl1] - b0;
-      const bool last = sl1 == n_slabs;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(nb, e->n_cus)), dim3(P2S_BS), 0,
-                         e->stream, A->d_bins + b0, nb, A->d_lrp, A->d_P, (int32_t)(A->p_alloc / 4 - 1), A->d_pslot,
-                         (const uint4 *)A->d_gblk, A->d_ptab, A->d_tlong, last ? A->n_tlong : 0, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
+    {
+      const TileChunk *ch = A->d_chunks;
+      const dim3 grid((unsigned)A->n_chunks), block(TBS);
+      if (A->n_chunks > 0) {
+        if (A->n_vdict && A->code_bits == 4)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), grid, block, 0, e->stream,
+                             ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+        else if (A->n_vdict)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), grid, block, 0, e->stream,
+                             ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+        else
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), grid, block, 0, e->stream,
+                             ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest, A->d_obase,
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+        HIP_TRY(e, hipGetLastError());
+      }
+    }
+    // phase 2; its reducer waves also add up the heavy rows' partials while the loaders fill the first bin
+    if (A->n_bins > 0) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
+                         e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(std::max<int64_t>(A->p_len, 4) / 4 - 1), A->d_pslot,
+                         (const uint4 *)A->d_gblk, A->d_ptab, A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
                          (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
@@ -1452,7 +1385,6 @@ int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, cons
     float ms = 0.f;
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
     *kernel_ns = (uint64_t)((double)ms * 1e6);
-    return check_gave_up(e);
   }
   return SH_OK;
 }
@@ -1521,7 +1453,6 @@ int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const s
     }
     HIP_TRY(e, hipMemcpyAsync(e->h_flag, e->d_flags, ITER_BATCH * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (int gu = check_gave_up(e)) return gu;
     int ran = nb;                          // launches of this batch that did run
     for (int k = 0; k < nb; k++)
       if (e->h_flag[k] == 0) { ran = k + 1; term = true; break; }
@@ -1549,3 +1480,142 @@ int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const s
 }
 
 } // extern "C"
+
+#ifdef SH_PLAN_EMULATE
+// Tools / CPU tests only (never in the product build): build the tiled plan on the host and execute BOTH phases
+// on the host, entry by entry, through exactly the tables the kernels read (fold flags, obase, gdest, gblk / ptab,
+// pslot, lrp) with the kernels' indexing.  A test that compares the result with a plain CSR product thereby
+// checks the layout without a GPU.  semiring: 0 = (+,x) float, 2 = (or,and) int32.  stats[0..7]: stream entries,
+// light entries, products, bins, chunks, heavy rows, P words never written but read (must be 0), tiles.
+namespace {
+struct HPlusTimes { using T = float; static T identity() { return 0.0f; } static T mul(T x, T a) { return x * a; } static T add(T a, T b) { return a + b; } };
+struct HOrAnd { using T = int32_t; static T identity() { return 0; } static T mul(T x, T a) { return (x != 0) && (a != 0); } static T add(T a, T b) { return (a != 0) || (b != 0); } };
+template <class T> T hbits(uint32_t u) { T v; memcpy(&v, &u, 4); return v; }
+template <class T> uint32_t tobits(T v) { uint32_t u; memcpy(&u, &v, 4); return u; }
+
+template <class SR>
+int emulate(const TiledHost &H, int64_t rows, int64_t cols, const uint32_t *x, uint32_t *y, int64_t *stats) {
+  using T = typename SR::T;
+  constexpr uint32_t POISON = 0x7FC0DEADu;
+  std::vector<uint32_t> P((size_t)H.p_len + 4, POISON), partial((size_t)H.n_partials + 1, POISON), xs((size_t)TCOLS + 4);
+  const bool coded = !H.vdict.empty();
+  auto value_at = [&](int64_t q) -> uint32_t {
+    if (!coded) return H.tval[(size_t)q];
+    if (H.code_bits == 4) return H.vdict[(H.tcode[(size_t)q >> 1] >> ((q & 1) * 4)) & 0xFu];
+    return H.vdict[H.tcode[(size_t)q]];
+  };
+  // ---- phase 1
+  for (const TileChunk &ch : H.chunks) {
+    if (ch.s >= ch.e) continue;
+    const int64_t c0 = (int64_t)ch.tile * TCOLS;
+    for (int i = 0; i < TCOLS; i++) xs[(size_t)i] = (c0 + i < cols) ? x[c0 + i] : tobits<T>(SR::identity());
+    xs[(size_t)TCOLS] = tobits<T>(SR::identity());
+    auto prod = [&](int64_t q, uint32_t colmask) { return SR::mul(hbits<T>(xs[H.tcol[(size_t)q] & colmask]), hbits<T>(value_at(q))); };
+    if (ch.hs > ch.s) {   // light chunk: blocks of 64 groups, compacted products
+      if (ch.s % 256 || ch.e % 4) return -10;
+      const int64_t gs = ch.s / 4, le = ch.e / 4;
+      for (int64_t blk = 0; gs + blk * 64 < le; blk++) {
+        int64_t pos = H.obase[(size_t)ch.ob0 + (size_t)blk];
+        for (int64_t g = gs + blk * 64; g < std::min(le, gs + blk * 64 + 64); g++) {
+          T acc = SR::identity();
+          bool open = false;
+          for (int k = 0; k < 4; k++) {
+            const int64_t q = g * 4 + k;
+            const T p = prod(q, 0x7FFFu);
+            acc = open ? SR::add(acc, p) : p;
+            open = (H.tcol[(size_t)q] & TCOL_FOLD) != 0;
+            if (!open) {
+              if (pos >= H.p_len) return -11;
+              P[(size_t)pos++] = tobits<T>(acc);
+            }
+          }
+          if (open) return -12;   // a run must end inside its group
+        }
+      }
+    } else {              // heavy chunk: strips of 16, segmented scan inside waves of 64 strips
+      const int64_t s0 = ch.s / HSTRIP, s1 = ch.e / HSTRIP, sbase = ch.pdelta / HSTRIP;
+      for (int64_t w0 = s0; w0 < s1; w0 += 64) {
+        T lane[64];
+        uint32_t d[64];
+        const int n = (int)std::min<int64_t>(64, s1 - w0);
+        for (int l = 0; l < n; l++) {
+          T t = SR::identity();
+          for (int i = 0; i < HSTRIP; i++) t = SR::add(t, prod((w0 + l) * HSTRIP + i, 0xFFFFu));
+          lane[l] = t;
+          d[l] = H.gdest[(size_t)(w0 + l - sbase)];
+        }
+        for (int l = 0; l < n; l++) {
+          if (!(d[l] & GD_LAST)) continue;
+          const int dist = (int)((d[l] >> GD_DIST_SHIFT) & 63u);
+          if (dist > l) return -13;
+          T t = lane[l - dist];
+          for (int k = l - dist + 1; k <= l; k++) t = SR::add(t, lane[k]);
+          partial[d[l] & GD_SLOT_MASK] = tobits<T>(t);
+        }
+      }
+    }
+  }
+  // ---- phase 2
+  int64_t poison_reads = 0;
+  std::vector<uint32_t> img((size_t)TBIN);
+  for (const RowBin &b : H.bins) {
+    std::fill(img.begin(), img.end(), POISON);
+    const int64_t n4 = b.n / 4;
+    for (int64_t k = 0; k < n4; k++) {
+      const uint32_t *rec = &H.gblk[((size_t)b.gb0 + (size_t)(k / 64)) * 4];
+      const int lane = (int)(k % 64);
+      uint32_t below = 0;
+      for (int l = 0; l < lane; l++) below += (rec[l / 32] >> (l % 32)) & 1u;
+      const uint32_t own = (rec[lane / 32] >> (lane % 32)) & 1u;
+      const int64_t pg = (int64_t)H.ptab[(size_t)b.pt0 + (size_t)std::max<int64_t>((int64_t)(rec[2] + below + own) - 1, 0)] + k;
+      if (pg < 0 || pg * 4 + 3 >= (int64_t)P.size()) return -20;
+      for (int i = 0; i < 4; i++) {
+        const uint16_t sl = H.pslot[(size_t)b.pstart + (size_t)(k * 4 + i)];
+        if (sl == TSLOT_PAD) continue;
+        if (sl >= TBIN) return -21;
+        if (img[sl] != POISON) return -22;   // two products in one slot
+        img[sl] = P[(size_t)(pg * 4 + i)];
+        if (img[sl] == POISON) poison_reads++;
+      }
+    }
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
+      if (H.lrp[(size_t)r] & 0x80000000u) continue;
+      const int64_t s = (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu) - b.csr0, e = (int64_t)(H.lrp[(size_t)r + 1] & 0x7FFFFFFFu) - b.csr0;
+      if (s < 0 || e > TBIN) return -23;
+      T acc = SR::identity();
+      for (int64_t j = s; j < e; j++) {
+        if (img[(size_t)j] == POISON) poison_reads++;
+        acc = SR::add(acc, hbits<T>(img[(size_t)j]));
+      }
+      y[r] = tobits<T>(acc);
+    }
+  }
+  for (const LongRow &lr : H.heavy) {
+    T acc = SR::identity();
+    for (int k = 0; k < lr.nslots; k++) {
+      if (partial[(size_t)lr.slot0 + k] == POISON) poison_reads++;
+      acc = SR::add(acc, hbits<T>(partial[(size_t)lr.slot0 + k]));
+    }
+    y[lr.row] = tobits<T>(acc);
+  }
+  if (stats) {
+    stats[0] = H.stream_len; stats[1] = H.light_entries; stats[2] = H.p_len; stats[3] = (int64_t)H.bins.size();
+    stats[4] = (int64_t)H.chunks.size(); stats[5] = (int64_t)H.heavy.size(); stats[6] = poison_reads;
+    stats[7] = (cols + TCOLS - 1) / TCOLS;
+  }
+  (void)rows;
+  return 0;
+}
+} // namespace
+
+extern "C" int sh_debug_emulate_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx,
+                                     const void *val, const sh_plan_options *opt_p, int semiring, const void *x, void *y, int64_t *stats) {
+  sh_plan_options opt;
+  if (opt_p) opt = *opt_p; else sh_plan_options_default(&opt);
+  TiledHost H;
+  if (!build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, 256, H)) return -1;
+  if (semiring == 0) return emulate<HPlusTimes>(H, rows, cols, (const uint32_t *)x, (uint32_t *)y, stats);
+  if (semiring == 2) return emulate<HOrAnd>(H, rows, cols, (const uint32_t *)x, (uint32_t *)y, stats);
+  return -2;
+}
+#endif

@@ -69,18 +69,6 @@ struct LongRow { int32_t row, slot0, nslots, pad; };
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 
-// Hand-off discipline of the fused launch (spmv_tiled_fused below; MI355X_MICROARCH.md "Workgroup
-// dispatch, XCD placement & inter-workgroup visibility"): bytes one workgroup produces for another
-// inside a launch (P, heavy partials) are stored write-through (sc1), every storing wave drains
-// vmcnt, the workgroup meets at a barrier, ONE lane bumps an agent-scope counter; the consumer polls
-// that counter with relaxed agent-scope loads and reads the bytes with sc1 loads only.
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
 // outstanding global load (s_waitcnt vmcnt(0)), which would serialise the register prefetch
 // of the next bin behind the current bin's LDS work; the kernels below exchange data between
@@ -377,7 +365,7 @@ __global__ __launch_bounds__(HFIX_BS) void spmv_heavy_fixup(
 // The same sum by ONE wave (bit-identical: lane l plays threads l, l+64, l+128, l+192 of the block
 // above).  Used by the wave-specialised phase 2, whose reducer waves are idle while the loaders
 // fill the first bin.
-template <class SR, bool SC1>
+template <class SR>
 __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__restrict__ partial, int lane,
                                          const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
                                          bool use_y, uint32_t *__restrict__ out, const StepDev &st) {
@@ -394,8 +382,8 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 #pragma unroll
       for (int w = 0; w < HFIX_BS / 64; w++) {
         const int k = k0 + u * HFIX_BS + w * 64 + lane;
-        // clamped: branch-free, all loads fly together (SC1: partials written by other workgroups of this launch)
-        v[u][w] = SC1 ? ld_agent(partial + lr.slot0 + min(k, lr.nslots - 1)) : partial[lr.slot0 + min(k, lr.nslots - 1)];
+        // clamped: branch-free, all loads fly together
+        v[u][w] = partial[lr.slot0 + min(k, lr.nslots - 1)];
       }
 #pragma unroll
     for (int u = 0; u < HU; u++)
@@ -451,9 +439,9 @@ __device__ inline void heavy_row_by_wave(const LongRow lr, const uint32_t *__res
 // 8 B algorithmic, but all of it streamed.
 // ===========================================================================
 #ifndef SH_TCOLS
-#define SH_TCOLS 32768
+#define SH_TCOLS 32760
 #endif
-constexpr int TCOLS = SH_TCOLS;         // columns per x tile (4 B each in LDS); a multiple of 4, < 65536
+constexpr int TCOLS = SH_TCOLS;         // columns per x tile (4 B each in LDS); a multiple of 8, < 32768: a column code has 15 bits
 constexpr int TBS = 1024;               // threads per phase-1 workgroup
 #ifndef SH_TBIN
 #define SH_TBIN 16384   // 32768: one 1024-thread WG per CU; 16384: two 512-thread WGs (measured 5 % faster)
@@ -466,11 +454,16 @@ constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #ifndef SH_P1_UNROLL
 #define SH_P1_UNROLL 2
 #endif
+#ifndef SH_P1_STORE
+#define SH_P1_STORE 2   // how phase 1 writes its compacted products: 0 dword stores, 1 one 1..4-dword store per lane, 2 via LDS as 16-byte stores
+#endif
+constexpr int P1_STG = 272;             // words of the LDS staging strip of one wave (256 products + alignment shift, padded)
 constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
 constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
+constexpr uint16_t TCOL_FOLD = 0x8000;     // light entries: this entry's product is folded into the next entry's (same row, same tile)
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
-static_assert(TCOLS % 4 == 0 && TCOLS < 65536 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile");
+static_assert(TCOLS % 8 == 0 && TCOLS < 32768 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile; bit 15 is the fold flag");
 // Heavy rows: every (row, tile) piece is padded to whole STRIPS of HSTRIP consecutive stream entries.  One
 // lane of phase 1 sums a strip (wide loads, 16 products in stream order); consecutive lanes whose strips
 // belong to the same piece are then combined by a segmented wave scan in DPP, and the last lane of each run
@@ -484,16 +477,15 @@ constexpr int HSTRIP = 16;
 constexpr int GD_DIST_SHIFT = 25;
 constexpr uint32_t GD_SLOT_MASK = (1u << GD_DIST_SHIFT) - 1, GD_LAST = 0x80000000u;
 
-// entries [s,e) of the stream (slab-major light runs, then the tiles' heavy runs); positions >= hs
-// belong to heavy rows.  A light product at stream position q goes to P[q + pdelta] (the slab's slot
-// of the P ring); slab = -1 for heavy chunks, whose pdelta is the stream position of the first heavy entry
-// (strip k of the heavy part covers entries [pdelta + 16 k, pdelta + 16 k + 16)).
-struct TileChunk { int32_t tile, s, e, hs, pdelta, slab, pad0, pad1; };
-// r0/nr: rows of the bin; csr0: CSR position of its first entry; cnt: real products;
-// n: products incl. padding; pstart: where the bin's slots start in pslot[] (bin-major); gb0 / pt0: its
-// first 64-group block in gblk[] / its first piece in ptab[]; slab: the slab (slot of the P ring) its
-// products travel in.
-struct RowBin { int32_t r0, nr, csr0, gb0, n, pstart, slab, pt0; };
+// entries [s,e) of the stream (the tiles' light runs, then the tiles' heavy runs); positions >= hs
+// belong to heavy rows.  Light chunks: ob0 = index in obase[] of the chunk's first block of 64 groups
+// (obase[b] = P position of the block's first product).  Heavy chunks: pdelta = stream position of the
+// first heavy entry (strip k of the heavy part covers entries [pdelta + 16 k, pdelta + 16 k + 16)).
+struct TileChunk { int32_t tile, s, e, hs, pdelta, ob0, pad1, pad2; };
+// r0/nr: rows of the bin; csr0: CSR position of its first entry; n: products incl. padding;
+// pstart: where the bin's slots start in pslot[] (bin-major); gb0 / pt0: its first 64-group block in
+// gblk[] / its first piece in ptab[].
+struct RowBin { int32_t r0, nr, csr0, gb0, n, pstart, pad0, pt0; };
 
 // Value coding (VC): when the matrix holds at most 256 distinct 4-byte values (always true for
 // pattern files, and for every file once the reference's int narrowing -- quirk A-3 -- has been
@@ -534,19 +526,16 @@ __device__ __forceinline__ typename SR::T seg_scan_wave(typename SR::T t, const 
 }
 
 // VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
-// WT: products / partials are handed to other workgroups of the SAME launch: write-through stores
-//     (the caller drains and signals).  xs: [TCOLS + 4] words of LDS, ds: [VDICT].
+// xs: [TCOLS + 4] words of LDS, ds: [VDICT].
 SH_STAT(__device__ uint64_t *g_p1_stats;)
 struct NoHook { __device__ void operator()() const {} };
-// staged(): called by every thread right after the barrier that publishes the x tile.  WT callers
-// signal the PREVIOUS chunk there: every wave has waited for its staging loads by then, and with
-// them (vmcnt counts in issue order) for the stores of the chunk before.
-template <class SR, int VC, bool WT, class Hook = NoHook>
+// staged(): called by every thread right after the barrier that publishes the x tile (SH_STATS builds stamp it).
+template <class SR, int VC, class Hook = NoHook>
 __device__ __forceinline__ void tiled_phase1_chunk(
-    const TileChunk ch, uint32_t *xs, uint32_t *ds, const void *__restrict__ tval_or_code,
+    const TileChunk ch, uint32_t *xs, uint32_t *ds, uint32_t *stg_all, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
-    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial, Hook staged = NoHook()) {
+    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, Hook staged = NoHook()) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
   // the value words of one group of 4 entries: 4 values, 4 one-byte codes, or 4 nibbles
@@ -555,7 +544,6 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   const VWord *__restrict__ tval = reinterpret_cast<const VWord *>(tval_or_code);
   const uint2 *__restrict__ tcol2 = reinterpret_cast<const uint2 *>(tcol);
   const int tid = threadIdx.x;
-  __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(P, 0, (int)p_bytes, 0x00020000);
   const int c0 = ch.tile * TCOLS;
   const uint32_t ident = to_bits<T>(SR::identity());
   if (VC && tid < VDICT)
@@ -566,8 +554,6 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   // first stream batch.  (LDS-DMA staging -- global_load_lds_dwordx4, no VGPR round trip -- was measured
   // neutral on the same box: 494-512 vs 494-497 us per SpMV.)  (Requesting it right behind the staging loads, so that its HBM latency runs
   // under the LDS writes, was measured SLOWER on the same box: 533 vs 508 us per SpMV.)
-  // Every wave waits for staging loads here, and with them -- vmcnt counts in issue order -- for the
-  // stores of the chunk it processed before: that is what lets a WT caller signal that chunk in staged().
   auto stage = [&](auto request_first) {
     if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
       // full tile, 16-byte aligned: 1 KiB per wave-instruction; every load is issued before the first
@@ -584,8 +570,6 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     } else {
       for (int i = tid; i < TCOLS; i += TBS)
         xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
-      if constexpr (WT)   // (a wave past the end of a partial tile has loaded nothing: drain the older stores explicitly)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     staged();
@@ -600,60 +584,130 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       v = make_uint4(ds[w & 0xFu], ds[(w >> 4) & 0xFu], ds[(w >> 8) & 0xFu], ds[(w >> 12) & 0xFu]);
     else
       v = w;
-    pr[0] = SR::mul(from_bits<T>(xs[c.x & 0xFFFFu]), from_bits<T>(v.x));
-    pr[1] = SR::mul(from_bits<T>(xs[c.x >> 16]), from_bits<T>(v.y));
-    pr[2] = SR::mul(from_bits<T>(xs[c.y & 0xFFFFu]), from_bits<T>(v.z));
-    pr[3] = SR::mul(from_bits<T>(xs[c.y >> 16]), from_bits<T>(v.w));
+    // (bit 15 of a column code is the fold flag)
+    pr[0] = SR::mul(from_bits<T>(xs[c.x & 0x7FFFu]), from_bits<T>(v.x));
+    pr[1] = SR::mul(from_bits<T>(xs[(c.x >> 16) & 0x7FFFu]), from_bits<T>(v.y));
+    pr[2] = SR::mul(from_bits<T>(xs[c.y & 0x7FFFu]), from_bits<T>(v.z));
+    pr[3] = SR::mul(from_bits<T>(xs[(c.y >> 16) & 0x7FFFu]), from_bits<T>(v.w));
   };
   // Both loops are software-pipelined: the loads of batch i+1 are issued before batch i is
   // consumed, so a wave always has one batch of loads in flight behind the stores it issues
   // (stores count in vmcnt on gfx9: without this every batch would wait out the previous
   // batch's write latency).  Loads are unconditional on clamped indices -- one basic block.
-  // ---- light entries: products go to P at the entry's own stream position (16-byte stores)
+  // ---- light entries.  A lane owns a group of 4 consecutive stream entries.  Entries of one row that fall into
+  // this tile lie next to each other inside a group (the plan packs them so) and carry the FOLD flag on all
+  // but the last: their products are summed here, in stream order, and only the sum travels through P --
+  // a fifth of the light products of a power-law matrix never leave the lane.  A group therefore yields 1..4
+  // products; they are stored compacted: the product count of the lanes below comes from three ballots, the P
+  // position of the wave's first product from obase[] (one scalar load per 64 groups; the plan builder counted
+  // the flags), so the wave's products form one contiguous run of P (how it is written: SH_P1_STORE below).
   // (ping-pong register sets A/B instead of a copy at the loop end: a copy would wait for the
   // loads it copies)
   // A chunk is either all light (hs == e) or all heavy (hs <= s): the plan builder cuts them apart.
   const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
   if (ch.hs > ch.s) {
     constexpr int S = TBS * U;
-    auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U]) {
+    const int gs = ch.s / 4, last_blk = (le - gs - 1) >> 6;
+    auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U], uint32_t (&ob)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
         const int g = min(gbase + k * TBS, le - 1);
         vw[k] = tval[g];
         c[k] = tcol2[g];
+        // the wave's 64 groups are one block of obase[] (chunks start on block boundaries): a scalar load
+        ob[k] = obase[ch.ob0 + __builtin_amdgcn_readfirstlane(min((gbase + k * TBS - gs) >> 6, last_blk))];
       }
     };
-    auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U]) {
+    // (the loop runs per WAVE: a wave goes on while its first group is inside the chunk, lanes past the end carry no
+    // products -- the store stage below hands quads of the wave's strip to lanes whether or not they had a group)
+    const int lane = tid & 63;
+    auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U], const uint32_t (&ob)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
         const int g = gbase + k * TBS;
-        if (g < le) {
+        if (g - lane < le) {   // wave-uniform
+          const bool valid = g < le;
           T pr[4];
           products(vw[k], c[k], pr);
-          if constexpr (WT) {
-            const v4u32 pv = {to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, (g * 4 + ch.pdelta) * 4, 0, 16);   // aux 16 = sc1
-          } else {
-            reinterpret_cast<uint4 *>(P + ch.pdelta)[g] = make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+          const bool f0 = (c[k].x & 0x8000u) != 0, f1 = (c[k].x & 0x80000000u) != 0, f2 = (c[k].y & 0x8000u) != 0;
+          const T a1 = f0 ? SR::add(pr[0], pr[1]) : pr[1];
+          const T a2 = f1 ? SR::add(a1, pr[2]) : pr[2];
+          const T a3 = f2 ? SR::add(a2, pr[3]) : pr[3];
+          const uint32_t e0 = f0 ? 0u : 1u, e1 = f1 ? 0u : 1u, e2 = f2 ? 0u : 1u, m = e0 + e1 + e2;   // products of this group - 1
+          const uint64_t bv = __ballot(valid), b0 = __ballot(valid && (m & 1u)), b1 = __ballot(valid && (m & 2u));
+          auto below = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+          const uint32_t pre = below(bv) + below(b0) + 2u * below(b1);   // products of the lanes below
+#if SH_P1_STORE == 0
+          // four predicated dword stores per lane (measured: 4x the store requests of 16-byte stores, +93 us per SpMV)
+          uint32_t *dst = P + (ob[k] + pre);
+          if (valid) {
+            if (e0) dst[0] = to_bits<T>(pr[0]);
+            if (e1) dst[e0] = to_bits<T>(a1);
+            if (e2) dst[e0 + e1] = to_bits<T>(a2);
+            dst[m] = to_bits<T>(a3);
           }
+#elif SH_P1_STORE == 1
+          // the lane's products compacted in registers, then ONE store of 1..4 dwords per lane
+          const uint32_t c0 = to_bits<T>(pr[0]), c1 = to_bits<T>(a1), c2 = to_bits<T>(a2), c3 = to_bits<T>(a3);
+          const uint32_t o0 = e0 ? c0 : (e1 ? c1 : (e2 ? c2 : c3));
+          const uint32_t p1 = e0, p2 = e0 + e1;                       // positions of c1, c2 when emitted; c3 sits at m
+          const uint32_t o1 = (e1 && p1 == 1u) ? c1 : ((e2 && p2 == 1u) ? c2 : c3);
+          const uint32_t o2 = (e2 && p2 == 2u) ? c2 : c3;
+          uint32_t *dst = P + (ob[k] + pre);
+          if (valid) {
+            if (m == 3u) { v4u32 v = {o0, o1, o2, c3}; __builtin_memcpy(dst, &v, 16); }
+            else if (m == 2u) { dst[0] = o0; dst[1] = o1; dst[2] = o2; }
+            else if (m == 1u) { dst[0] = o0; dst[1] = o1; }
+            else dst[0] = o0;
+          }
+#else
+          // Compaction through a wave-private strip of LDS, then full 16-byte stores: the wave's products land in
+          // stg[] at the position they have in P modulo 4 (sh = P position of the wave's first product mod 4), lane L
+          // then owns the aligned quad L of the strip: one ds_read_b128 + one 16-byte store; the (at most two) partial
+          // quads at the ends of the wave's run go out as dword stores.  One wave's LDS traffic is served in issue order:
+          // the reads see the writes in front of them and the next group's writes come behind these reads -- no barrier.
+          uint32_t *stg = stg_all + (tid >> 6) * P1_STG;
+          const uint32_t sh = ob[k] & 3u;
+          const uint32_t T1 = (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);   // the wave's products
+          uint32_t *w = stg + sh + pre;
+          if (valid) {
+            if (e0) w[0] = to_bits<T>(pr[0]);
+            if (e1) w[e0] = to_bits<T>(a1);
+            if (e2) w[e0 + e1] = to_bits<T>(a2);
+            w[m] = to_bits<T>(a3);
+          }
+          const uint32_t end = sh + T1;
+          uint32_t *pb = P + (ob[k] - sh);                               // P address of stg[0]: a multiple of 4 products
+          auto put_quad = [&](uint32_t lo) {
+            if (lo >= sh && lo + 4u <= end) {
+              *reinterpret_cast<uint4 *>(pb + lo) = *reinterpret_cast<const uint4 *>(stg + lo);
+            } else if (lo < end && lo + 4u > sh) {
+#pragma unroll
+              for (uint32_t i = 0; i < 4u; i++)
+                if (lo + i >= sh && lo + i < end) pb[lo + i] = stg[lo + i];
+            }
+          };
+          put_quad(4u * (uint32_t)lane);                                 // quads 0..63 by lane
+          if (end > 256u && lane == 0) put_quad(256u);                   // quad 64: at most 3 products
+#endif
         }
       }
     };
     VWord va[U], vb[U];
     uint2 ca[U], cb[U];
-    int g0 = ch.s / 4 + tid;
-    stage([&]() { load(g0, va, ca); });
-    if (g0 < le) {
+    uint32_t oa[U], obb[U];
+    int g0 = gs + tid;
+    stage([&]() { load(g0, va, ca, oa); });
+    if (g0 - lane < le) {
       for (;;) {
-        load(g0 + S, vb, cb);
-        consume(g0, va, ca);
+        load(g0 + S, vb, cb, obb);
+        consume(g0, va, ca, oa);
         g0 += S;
-        if (g0 >= le) break;
-        load(g0 + S, va, ca);
-        consume(g0, vb, cb);
+        if (g0 - lane >= le) break;
+        load(g0 + S, va, ca, oa);
+        consume(g0, vb, cb, obb);
         g0 += S;
-        if (g0 >= le) break;
+        if (g0 - lane >= le) break;
       }
     }
   }
@@ -701,10 +755,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       }
       if (!valid) t = SR::identity();   // (clamped reload of the chunk's last strip: must not join a run)
       t = seg_scan_wave<SR>(t, valid ? (int)((d >> GD_DIST_SHIFT) & 63u) : 0, lane);
-      if (valid && (d & GD_LAST)) {
-        if constexpr (WT) st_agent(partial + (d & GD_SLOT_MASK), to_bits<T>(t));
-        else partial[d & GD_SLOT_MASK] = to_bits<T>(t);
-      }
+      if (valid && (d & GD_LAST))
+        partial[d & GD_SLOT_MASK] = to_bits<T>(t);
     };
     SWord va[NV], vb[NV];
     uint4 ca[2], cb[2];
@@ -731,17 +783,18 @@ template <class SR, int VC>
 __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
-    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t p_bytes, uint32_t *__restrict__ partial, const int32_t *gate) {
+    const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate) {
   __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC ? VDICT : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t stg[SH_P1_STORE == 2 ? (TBS / 64) * P1_STG : 4];
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e || (gate != nullptr && *gate == 0))
     return;   // filler that keeps the XCD-aligned chunk order / the iteration loop is over (StepDev::gate)
   SH_STAT(const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime(); __shared__ uint64_t st_staged;)
   SH_STAT(auto stamp = [&]() { if (threadIdx.x == 0) st_staged = __builtin_amdgcn_s_memrealtime(); };)
 #ifdef SH_STATS
-  tiled_phase1_chunk<SR, VC, false>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial, stamp);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, stg, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, stamp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && g_p1_stats) {   // per chunk: kind, entries, start, staged, end (100 MHz ticks)
@@ -749,7 +802,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     S[0] = ch.hs <= ch.s; S[1] = (uint64_t)(ch.e - ch.s); S[2] = st_t0; S[3] = st_staged; S[4] = __builtin_amdgcn_s_memrealtime();
   }
 #else
-  tiled_phase1_chunk<SR, VC, false>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, x, cols, P, p_bytes, partial);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, stg, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial);
 #endif
 }
 
@@ -807,60 +860,17 @@ struct P2Lds {
   int32_t rp[2][TBIN_ROWS + 1];
   uint32_t dots[TBIN_ROWS];
   ReduceScratch<P2S_RD, TBIN> sc;
-  int32_t ready_slab;   // fused launch: THIS slab is known to be written (published by a reducer; gates open in any order)
 };
 
-// Gates: the fused launch's hand-off points ("all chunks of slab s are written", "all bins of slab s
-// are read", "all heavy chunks are done").  A gate is 64 words of the control block: word 0 counts
-// arrivals (touched by atomics only), word 32 -- a 128-B line of its own -- is the flag the LAST
-// arriver sets and the waiters poll.  Waiters never poll the counter: a few hundred pollers on the
-// word the producers' atomics target delayed those atomics (and everything in-order behind them in
-// the producers' vmcnt) by tens of microseconds.  Polls back off to ~4 us.
-constexpr int GATE_WORDS = 64, GATE_FLAG = 32;
-__device__ __forceinline__ uint32_t gate_arrive(uint32_t *gate) {   // returns the arrivals before this one
-  return __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void gate_finish(uint32_t *gate, uint32_t before, uint32_t need) {
-  if (before + 1 == need) st_agent(gate + GATE_FLAG, 1u);
-}
-__device__ __forceinline__ bool gate_is_open(const uint32_t *gate) { return ld_agent(gate + GATE_FLAG) != 0; }
-// Bounded wait (wave-uniform); a give-up sets *err (host-visible) and lets the caller run on, so that
-// the grid always drains; after the first give-up nothing waits any more.
-constexpr uint32_t SPIN_LIMIT = 1u << 19;   // x ~2-4 us
-__device__ __forceinline__ void gate_wait(const uint32_t *gate, uint32_t *err, bool &gave_up, uint64_t *ticks = nullptr) {
-  uint32_t spins = 0;
-  SH_STAT(const uint64_t t0 = __builtin_amdgcn_s_memrealtime();)
-  while (!gave_up && !gate_is_open(gate)) {
-    if (spins < 4) __builtin_amdgcn_s_sleep(8);
-    else if (spins < 16) __builtin_amdgcn_s_sleep(32);
-    else __builtin_amdgcn_s_sleep(127);
-    if (++spins > SPIN_LIMIT) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gave_up = true;
-    }
-  }
-  SH_STAT(if (ticks) *ticks += __builtin_amdgcn_s_memrealtime() - t0;)
-}
-__device__ __forceinline__ void async_load_sc1(v4u32 &dst, const void *addr) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(addr) : "memory");
-}
-
 // One workgroup's share of phase 2: bins b0, b0 + stride, ... (nb of them) of bins[].
-// FUSED: the bins' products are written by phase-1 workgroups of the SAME launch: before a loader
-// wave issues the first P load of a bin in a new slab that slab's "written" gate must be open (a
-// reducer lane polls it two bins ahead and publishes the result in LDS, so that the loaders' vmcnt
-// window is normally not disturbed; otherwise the loader waits itself); P is read with sc1 loads;
-// after a bin's image is complete one lane arrives at the slab's "read" gate (the ring slot may be
-// overwritten once all of the slab's bins did).  gates: [written(s)], then [read(s)], s < n_slabs.
-template <class SR, bool FUSED>
+template <class SR>
 __device__ __forceinline__ void tiled_phase2_run(
     P2Lds &L, const RowBin *__restrict__ bins, const int b0, const int nb, const int stride,
     const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ P, int32_t last_group,
     const uint16_t *__restrict__ pslot, const uint4 *__restrict__ gblk, const int32_t *__restrict__ ptab,
     const LongRow *__restrict__ heavy_rows, int32_t n_heavy, int32_t heavy_first, int32_t heavy_stride,
     const uint32_t *__restrict__ heavy_partial, const uint32_t *__restrict__ y, typename SR::T alpha,
-    typename SR::T beta, const bool use_y, uint32_t *__restrict__ out, const StepDev &st,
-    uint32_t *gates, int32_t n_slabs, const int32_t *__restrict__ need, uint32_t *err, uint64_t *wait_ticks = nullptr, uint64_t *slab_t = nullptr) {
+    typename SR::T beta, const bool use_y, uint32_t *__restrict__ out, const StepDev &st) {
   auto &prod = L.prod;
   auto &rp = L.rp;
   auto &dots = L.dots;
@@ -871,28 +881,11 @@ __device__ __forceinline__ void tiled_phase2_run(
   auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * stride]; };   // clamped: scalar loads
   if (tid < 8)
     sc.cnt[tid] = 0;
-  if (FUSED && tid == 8)
-    L.ready_slab = -1;
   lds_barrier();
 
   if (tid < P2S_LD) {
     // ------------------------------------------------------------------ loaders
     const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
-    int ready_slab = -1;   // this wave has seen the gates of its bins' slabs up to this one open (FUSED)
-    bool gave_up = false;
-    // (the wait for the NEXT bin's slab happens while the current bin is unfinished: the host makes sure
-    // that a worker's next bin is at most one slab ahead and that the ring has two slots or more, so the
-    // chunks waited for never depend on this bin's completion)
-    auto ensure = [&](const RowBin &bn) {
-      if constexpr (FUSED) {
-        if (bn.slab > ready_slab) {
-          const int pub = *(volatile int32_t *)&L.ready_slab;   // (exactly this slab: an open gate says nothing about earlier slabs)
-          if (pub != bn.slab && need[2 * bn.slab] > 0)
-            gate_wait(gates + bn.slab * GATE_WORDS, err, gave_up, wait_ticks);
-          ready_slab = bn.slab;
-        }
-      }
-    };
     // Where the products of step q = 4*j + quarter lie in P.  The bin's groups are laid out piece by piece (one piece
     // per column tile); instead of a source address per group (1 B per product of HBM traffic) the plan keeps, per
     // 64 groups, a record {mask of the groups that start a piece, pieces started before the block} -- one scalar
@@ -933,14 +926,7 @@ __device__ __forceinline__ void tiled_phase2_run(
         async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
         // (clamped: a stale register must not fault)
         const int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
-#if defined(SH_FORCE_WT)
-        async_load_sc1(p[k], P4 + pg);
-#elif defined(SH_NO_SC1)
         async_load(p[k], P4 + pg);
-#else
-        if constexpr (FUSED) async_load_sc1(p[k], P4 + pg);
-        else async_load(p[k], P4 + pg);
-#endif
       }
     };
     auto wait8 = [&](v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K], uint32_t (&g)[P2S_K]) {
@@ -978,7 +964,6 @@ __device__ __forceinline__ void tiled_phase2_run(
         g[0][k] = (uint32_t)*ptab_index(cur, record_of(cur, 0, k));
         g[1][k] = (uint32_t)*ptab_index(b1, record_of(b1, 1 % P2S_NS, k));
       }
-      ensure(cur);
       issue_ps(cur, 0, g[0], p[0], sl[0]);
       fetch_rec(bin_of(2), 2 % P2S_NS);
       issue_gs(bin_of(2), g[0]);
@@ -995,8 +980,6 @@ __device__ __forceinline__ void tiled_phase2_run(
           scatter(img, cur, s, p[a], sl[a]);
           issue_gs(bin_of(s + 3), g[a ^ 1]);                          // piece words of step q+3 (records fetched a step ago)
           fetch_rec(bin_of(s + 4), (s + 4) % P2S_NS);                 // records of step q+4
-          if ((s + 2) % P2S_NS == 0)
-            ensure(bin_of(s + 2));                         // first P load of the next bin
           issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
           if (s == P2S_NS / 2 - 1)
             lds_barrier();   // MID
@@ -1016,18 +999,8 @@ __device__ __forceinline__ void tiled_phase2_run(
     // ------------------------------------------------------------------ reducers
     const int rt = tid - P2S_LD;
     RowBin prev = bin_at(0);
-    int pub = -1;   // FUSED: the slab lane rt == 64 has published as written
     for (int j = 0; j <= nb; j++) {
       const RowBin cur = bin_at(j);
-      // FUSED, one lane: is the slab of the bin after next written?  (asked here, looked at after the reduction)
-      int want = -1;
-      bool open = false;
-      if constexpr (FUSED) {
-        if (rt == 64 && j + 2 < nb) {
-          want = bins[b0 + (j + 2) * stride].slab;
-          if (want > pub) open = need[2 * want] == 0 || gate_is_open(gates + want * GATE_WORDS);
-        }
-      }
       // row offsets of the bin being streamed now (needed by the next reduction)
       uint32_t rr[P2S_RPU];
       if (j < nb) {
@@ -1053,7 +1026,7 @@ __device__ __forceinline__ void tiled_phase2_run(
         // nothing to reduce yet (the loaders are filling the first image): add up the heavy rows'
         // phase-1 partials meanwhile, one row per wave
         for (int h = heavy_first + (rt >> 6); h < n_heavy; h += heavy_stride)
-          heavy_row_by_wave<SR, false>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
+          heavy_row_by_wave<SR>(heavy_rows[h], heavy_partial, rt & 63, y, alpha, beta, use_y, out, st);
         lds_barrier();   // MID
         if (staged)
           lds_barrier(); // MID2
@@ -1069,22 +1042,6 @@ __device__ __forceinline__ void tiled_phase2_run(
           }
       }
       lds_barrier();     // END
-      if constexpr (FUSED) {
-        if (rt == 64 && want > pub && open) {
-          *(volatile int32_t *)&L.ready_slab = want;   // (loaders look at it at their step 2 of the next bin)
-          pub = want;
-        }
-        // Every loader wave has scattered bin j: all of its P loads have landed, the ring slot may go once
-        // all of the slab's bins said so.  Arrival from a reducer lane (in a loader wave the atomic would sit
-        // in the hand-counted vmcnt window), and its outcome is looked at right away: a worker must never
-        // block -- its loaders may, on the next slab -- while the flag it owes is unset.
-        if (rt == 0 && j < nb) {
-          uint32_t *g = gates + (n_slabs + cur.slab) * GATE_WORDS;
-          const uint32_t before = gate_arrive(g);
-          SH_STAT(if (slab_t && (int32_t)before + 1 == need[2 * cur.slab + 1]) slab_t[2 * cur.slab + 1] = __builtin_amdgcn_s_memrealtime();)
-          gate_finish(g, before, (uint32_t)need[2 * cur.slab + 1]);
-        }
-      }
       prev = cur;
     }
   }
@@ -1108,193 +1065,10 @@ __global__ __launch_bounds__(P2S_BS) void spmv_tiled_phase2s(
   if (b0 >= n_bins)
     return;
   const int nb = (n_bins - b0 + G - 1) / G;    // bins of this workgroup: b0, b0+G, ...
-  tiled_phase2_run<SR, false>(L, bins, b0, nb, G, row_ptr, P, last_group, pslot, gblk, ptab, heavy_rows, n_heavy,
-                              (int)blockIdx.x * (P2S_RD / 64), G * (P2S_RD / 64), heavy_partial, y, alpha, beta,
-                              use_y_i != 0, out, st, nullptr, 0, nullptr, nullptr);
+  tiled_phase2_run<SR>(L, bins, b0, nb, G, row_ptr, P, last_group, pslot, gblk, ptab, heavy_rows, n_heavy,
+                       (int)blockIdx.x * (P2S_RD / 64), G * (P2S_RD / 64), heavy_partial, y, alpha, beta,
+                       use_y_i != 0, out, st);
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// The tiled plan as ONE persistent launch (default).  One 1024-thread workgroup per CU; workgroups
-// are split into two roles that run side by side on different CUs:
-//   phase-1 workers  claim chunks from per-XCD queues (slab-major; chunk of tile t in queue t % 8 so
-//                    that an XCD's L2 only stages its own eighth of x), stage the x tile, write the
-//                    slab's products into its slot of the P ring (write-through);
-//   phase-2 workers  walk the row bins in order (wave-specialised loaders/reducers as above) and
-//                    wait at each slab boundary until all of the slab's chunks have signalled.
-// A product is therefore re-read a few tens of microseconds after it was written and its line is
-// overwritten `ring` slabs later: P lives in the 256 MiB Infinity Cache and never costs HBM time
-// (profiles/r02_lab_slab_mall_ring_microbench.log: 7.9 instead of 5.3 TB/s for the same bytes).
-// Dependencies, all through gates in `ctl` (zeroed before every launch):
-//   chunk of slab s   needs gate read(s - ring): all bins of that slab consumed, ring slot free
-//   bin of slab s     needs gate written(s): all chunks of the slab stored
-//   heavy rows        need gate heavy: all heavy chunks stored
-// Both queues are claimed in slab order, so every wait is for items that running workgroups
-// already hold: no cycle as long as all workgroups are resident (grid == CU count, one per CU by
-// LDS).  Every spin is bounded (gate_wait) and reports through a host-visible error word.
-// When their own work is done, workers of both roles drain the heavy-chunk queue (phase-1 work
-// that touches no slab) and then add up the heavy rows' partials.
-struct FusedDev {
-  const TileChunk *qchunks;      // 8 light-chunk queues, concatenated; queue q = [lq0[q], lq0[q+1])
-  const int32_t *lq0;            // [9]
-  const TileChunk *hchunks;      // heavy chunks
-  int32_t n_hchunks, cols;
-  const void *tval;              // raw value words or value codes
-  const uint32_t *vdict;
-  const uint16_t *tcol;
-  const uint32_t *gdest;
-  const uint32_t *x;
-  uint32_t *P;
-  uint32_t p_bytes;
-  int32_t last_group;
-  uint32_t *partial;
-  const RowBin *bins;
-  const int32_t *lrp;
-  const uint16_t *pslot;
-  const uint4 *gblk;
-  const int32_t *ptab;
-  const LongRow *heavy_rows;
-  const int32_t *need;           // [2 * n_slabs]: {light chunks, bins} of each slab
-  uint32_t *ctl;
-  uint32_t *err;                 // host-visible word: set when a bounded spin gave up
-  uint64_t *stats;               // SH_STATS builds: 8 words per workgroup
-  int32_t dbg;                   // SH_STATS builds: 1 = phase-1 workers only signal, 2 = phase-2 workers only signal
-  int32_t n_bins, n_heavy, n_slabs, ring, n2;
-};
-// ctl words: queue head of slot q at q * 16 (64 B apart), then
-constexpr int CTL_HHEAD = 128, CTL_GATES = 192;   // gates: heavy, written(0..S-1), read(0..S-1)
-
-template <class SR, int VC>
-__global__ __launch_bounds__(P2S_BS) void spmv_tiled_fused(
-    const FusedDev D, const uint32_t *__restrict__ y, typename SR::T alpha, typename SR::T beta,
-    int use_y_i, uint32_t *__restrict__ out, StepDev st) {
-  static_assert(P2S_BS == TBS, "both roles use the whole workgroup");
-  if (gate_closed(st))
-    return;
-  __shared__ union { P2Lds p2; uint32_t xs[TCOLS + 4]; } U;
-  __shared__ uint32_t ds[VC ? VDICT : 1];
-  __shared__ int32_t claim;
-  const int tid = threadIdx.x;
-  const int slot = blockIdx.x & 7, k = blockIdx.x >> 3;
-  uint32_t *const ctl = D.ctl;
-  uint32_t *const gate_heavy = ctl + CTL_GATES, *const gates = gate_heavy + GATE_WORDS, *const err = D.err;
-  const bool use_y = use_y_i != 0;
-  bool gave_up = false;
-  SH_STAT(uint64_t st_wait = 0, st_items = 0, st_heavy = 0; const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime();)
-  SH_STAT(__shared__ uint64_t st_p2wait;)
-
-  // Queues are claimed one ticket ahead: the atomic for the NEXT item flies while the current one is
-  // processed (a returning atomic costs 1-3 us under load).  Workgroup-uniform result, -1 = exhausted.
-  uint32_t ticket = 0;   // thread 0 only
-  auto claim_first = [&](uint32_t *head) {
-    if (tid == 0) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto claim_next = [&](uint32_t *head, int32_t n) -> int32_t {
-    if (tid == 0) {
-      claim = ticket < (uint32_t)n ? (int32_t)ticket : -1;
-      if (ticket < (uint32_t)n) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const int32_t c = claim;
-    __syncthreads();   // (also: every wave is done with the LDS of the previous item)
-    return c;
-  };
-  // A chunk's completion is signalled one chunk late, from inside the next chunk (see tiled_phase1_chunk),
-  // or by flush() when the worker leaves phase-1 work: nobody waits out a store drain per chunk.
-  int pend = -2;          // slab of the chunk whose signal is pending (-1: heavy, -2: none); workgroup-uniform
-  int ring_free = D.ring - 1;   // slabs up to this one are known to have a free ring slot; workgroup-uniform
-  // arrival of a finished chunk at its gate (thread 0); the outcome is looked at later (finish_arrival)
-  uint32_t arr_before = 0;
-  int arr_slab = -2;
-  auto gate_of = [&](int slab) { return slab >= 0 ? gates + slab * GATE_WORDS : gate_heavy; };
-  auto need_of = [&](int slab) { return (uint32_t)(slab >= 0 ? D.need[2 * slab] : D.n_hchunks); };
-  auto arrive = [&](int slab) {
-    arr_before = gate_arrive(gate_of(slab));
-    arr_slab = slab;
-  };
-  auto finish_arrival = [&]() {
-    if (arr_slab != -2) {
-      SH_STAT(if (D.stats && arr_slab >= 0 && arr_before + 1 == need_of(arr_slab)) D.stats[4096 + 2 * arr_slab] = __builtin_amdgcn_s_memrealtime();)
-      gate_finish(gate_of(arr_slab), arr_before, need_of(arr_slab));
-      arr_slab = -2;
-    }
-  };
-  auto flush = [&]() {
-    if (pend != -2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-      __syncthreads();
-      if (tid == 0) { finish_arrival(); arrive(pend); finish_arrival(); }
-      pend = -2;
-    }
-  };
-  auto run_chunk = [&](const TileChunk ch) {
-    if (ch.slab > ring_free) {   // the ring slot must have been read completely (checked once per slab)
-      flush();                   // (what is waited for may itself be waiting for this worker's pending signal)
-      if (tid == 0)
-        gate_wait(gates + (D.n_slabs + ch.slab - D.ring) * GATE_WORDS, err, gave_up SH_STAT(, &st_wait));
-      ring_free = ch.slab;
-    }
-    __syncthreads();
-    const int prev = pend;
-    // (the previous chunk's arrival is issued behind this chunk's staging barrier and looked at after the
-    // chunk: the returning atomic never stalls the stream)
-    auto staged = [&]() { if (tid == 0 && prev != -2) { finish_arrival(); arrive(prev); } };
-    SH_STAT(if (D.dbg & 1) { staged(); pend = ch.slab; return; })
-#ifdef SH_NO_SC1   // tuning builds: plain stores (results invalid; timing only)
-    tiled_phase1_chunk<SR, VC, false>(ch, U.xs, ds, D.tval, D.vdict, D.tcol, D.gdest, D.x, D.cols, D.P, D.p_bytes, D.partial, staged);
-#else
-    tiled_phase1_chunk<SR, VC, true>(ch, U.xs, ds, D.tval, D.vdict, D.tcol, D.gdest, D.x, D.cols, D.P, D.p_bytes, D.partial, staged);
-#endif
-    if (tid == 0) finish_arrival();
-    pend = ch.slab;
-  };
-
-  if (k < D.n2) {
-    // ---------------------------------------------------------------- phase-2 worker
-    const int v = slot * D.n2 + k, N2 = 8 * D.n2;   // consecutive bins on one XCD (see spmv_tiled_phase2s)
-    if (v < D.n_bins) {
-      const int nb = (D.n_bins - v + N2 - 1) / N2;
-      SH_STAT(uint64_t w = 0;)
-      SH_STAT(if (D.dbg & 2) { for (int j = tid; j < nb; j += P2S_BS) { const int sl = D.bins[v + j * N2].slab; uint32_t *g = gates + (D.n_slabs + sl) * GATE_WORDS;
-                                 gate_finish(g, gate_arrive(g), (uint32_t)D.need[2 * sl + 1]); } } else)
-      tiled_phase2_run<SR, true>(U.p2, D.bins, v, nb, N2, D.lrp, D.P, D.last_group, D.pslot, D.gblk, D.ptab, nullptr, 0, 0, 1,
-                                 nullptr, y, alpha, beta, use_y, out, st, gates, D.n_slabs, D.need, err SH_STAT(, &w, D.stats ? D.stats + 4096 : nullptr));
-      SH_STAT(if (tid == 0) st_p2wait = w; __syncthreads(); st_wait = st_p2wait; st_items = nb;)
-    }
-  } else {
-    // ---------------------------------------------------------------- phase-1 worker
-    for (int dq = 0; dq < 8; dq++) {   // its own XCD's queue first, then the others'
-      const int q = (slot + dq) & 7;
-      const int32_t q0 = D.lq0[q], n = D.lq0[q + 1] - q0;
-      claim_first(ctl + q * 16);
-      for (;;) {
-        const int32_t c = claim_next(ctl + q * 16, n);
-        if (c < 0) break;
-        run_chunk(D.qchunks[q0 + c]);
-        SH_STAT(st_items++;)
-      }
-    }
-  }
-  SH_STAT(const uint64_t st_t1 = __builtin_amdgcn_s_memrealtime();)
-  // ------------------------------------------------------------------ both: heavy chunks, then heavy rows
-  claim_first(ctl + CTL_HHEAD);
-  for (;;) {
-    const int32_t c = claim_next(ctl + CTL_HHEAD, D.n_hchunks);
-    if (c < 0) break;
-    run_chunk(D.hchunks[c]);
-    SH_STAT(st_heavy++;)
-  }
-  flush();
-  SH_STAT(const uint64_t st_t2 = __builtin_amdgcn_s_memrealtime();)
-  if (D.n_heavy > 0) {
-    if (tid == 0 && D.n_hchunks > 0)
-      gate_wait(gate_heavy, err, gave_up);
-    __syncthreads();
-    for (int h = (int)blockIdx.x * (P2S_BS / 64) + (tid >> 6); h < D.n_heavy; h += (int)gridDim.x * (P2S_BS / 64))
-      heavy_row_by_wave<SR, true>(D.heavy_rows[h], D.partial, tid & 63, y, alpha, beta, use_y, out, st);
-  }
-  SH_STAT(if (tid == 0 && D.stats) { uint64_t *S = D.stats + (size_t)blockIdx.x * 8; S[0] = k < D.n2; S[1] = st_items; S[2] = st_t0;
-            S[3] = st_t1; S[4] = st_t2; S[5] = st_wait; S[6] = st_heavy; S[7] = __builtin_amdgcn_s_memrealtime(); })
-}
 
 } // namespace sh

@@ -88,6 +88,12 @@ class CsrMatrix:
         self.engine._chk(abi.load().sh_csr_describe(self.h, buf, len(buf)))
         return buf.value.decode()
 
+    def footprint(self):
+        """Device bytes held by this matrix."""
+        b = C.c_uint64()
+        self.engine._chk(abi.load().sh_csr_footprint(self.h, C.byref(b)))
+        return b.value
+
     def free(self):
         if self.h is not None:
             abi.load().sh_csr_free(self.engine.h, self.h)
@@ -140,7 +146,7 @@ class Engine:
 
     # ---- buffers
     def upload_csr(self, rows, cols, row_ptr, col_idx, val, **options):
-        """options: fields of sh_plan_options (plan=0|1|2, value_coding=0|8|-1, fused=1, ...) on top of the
+        """options: fields of sh_plan_options (plan=0|1|2, value_coding=0|8|-1, fold=0, ...) on top of the
         SH_* environment; without any the environment alone decides (sh_csr_upload)."""
         row_ptr = np.ascontiguousarray(row_ptr, np.int32)
         col_idx = np.ascontiguousarray(col_idx, np.int32)

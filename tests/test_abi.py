@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(abi.SIGNATURES) == names, "abi.SIGNATURES and the header disagree"
-    assert lib.sh_abi_version() == 1
+    assert lib.sh_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device():
@@ -62,14 +62,13 @@ def test_plan_options_defaults_and_environment(monkeypatch):
     lib = abi.load()
     o = abi.sh_plan_options()
     lib.sh_plan_options_default(C.byref(o))
-    assert (o.plan, o.autotune, o.value_coding, o.heavy_per_tile, o.xcd_order, o.fused, o.ring) == (0, 1, 0, 8, 1, 0, 3)
-    assert o.chunk == 0 and o.slab_mb == 0
-    for k, v in {"SH_PLAN": "tiled", "SH_VALCODE": "off", "SH_AUTOTUNE": "0", "SH_FUSED": "1", "SH_SLAB_MB": "0.5",
-                 "SH_RING": "2", "SH_N2": "3", "SH_HEAVY_PER_TILE": "4", "SH_BUILD_THREADS": "2"}.items():
+    assert (o.plan, o.autotune, o.value_coding, o.heavy_per_tile, o.xcd_order, o.fold) == (0, 1, 0, 8, 1, 1)
+    assert o.chunk == 0
+    for k, v in {"SH_PLAN": "tiled", "SH_VALCODE": "off", "SH_AUTOTUNE": "0", "SH_FOLD": "0",
+                 "SH_HEAVY_PER_TILE": "4", "SH_BUILD_THREADS": "2", "SH_CHUNK": "4096"}.items():
         monkeypatch.setenv(k, v)
     lib.sh_plan_options_from_env(C.byref(o))
-    assert (o.plan, o.value_coding, o.autotune, o.fused, o.ring, o.n2, o.heavy_per_tile, o.build_threads) == (2, -1, 0, 1, 2, 3, 4, 2)
-    assert o.slab_mb == 0.5
+    assert (o.plan, o.value_coding, o.autotune, o.fold, o.heavy_per_tile, o.build_threads, o.chunk) == (2, -1, 0, 0, 4, 2, 4096)
     monkeypatch.setenv("SH_VALCODE", "8")
     monkeypatch.setenv("SH_PLAN", "stream")
     lib.sh_plan_options_from_env(C.byref(o))

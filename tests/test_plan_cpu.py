@@ -1,0 +1,126 @@
+"""The x-tiled two-phase plan, checked WITHOUT a GPU: a tools build of the engine (-DSH_PLAN_EMULATE) exports
+sh_debug_emulate_plan, which builds the device layout exactly as sh_csr_upload does and then walks both phases on
+the host through the very tables the kernels read (fold flags, obase, gdest, gblk / ptab, pslot, lrp) with the
+kernels' indexing.  Comparing its result with a plain CSR product checks the layout builder: run folding (runs of
+1..4 entries, padding entries that join a run or make a padding product), piece tables, heavy strips and their
+partial slots.  The device code itself is covered by the -m gpu parity tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from sparseharness_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sparseharness_amd", "csrc")
+LIB = os.path.join(ROOT, "sparseharness_amd", "variants", "emulate.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    src = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "semiring.hip.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-ffp-contract=off", "-Wno-unused-function", "-DSH_PLAN_EMULATE", src[0], "-o", LIB])
+    lib = C.CDLL(LIB)
+    lib.sh_plan_options_default.argtypes = [C.POINTER(abi.sh_plan_options)]
+    lib.sh_debug_emulate_plan.restype = C.c_int
+    lib.sh_debug_emulate_plan.argtypes = [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.POINTER(abi.sh_plan_options), C.c_int,
+                                                                                C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def emulate(lib, rows, cols, rp, ci, va, sem, **options):
+    opt = abi.sh_plan_options()
+    lib.sh_plan_options_default(C.byref(opt))
+    opt.plan = 2
+    for k, v in options.items():
+        setattr(opt, k, v)
+    x = (1 + np.arange(cols) % 7).astype(np.float32) if sem == 0 else (np.arange(cols) % 3 == 0).astype(np.int32)
+    y = np.zeros(rows, np.float32 if sem == 0 else np.int32)
+    st = np.zeros(8, np.int64)
+    rc = lib.sh_debug_emulate_plan(rows, cols, len(ci), _p(rp), _p(ci), _p(va), C.byref(opt), sem, _p(x), _p(y), _p(st))
+    return rc, y, dict(zip(("stream", "light", "products", "bins", "chunks", "heavy_rows", "poison_reads", "tiles"), st.tolist())), x
+
+
+def exact(rows, cols, rp, ci, va, x, sem):
+    ok = (ci >= 0) & (ci < cols)
+    xv = np.where(ok, x[np.clip(ci, 0, cols - 1)], 0)
+    row_of = np.repeat(np.arange(rows), np.diff(rp))
+    if sem == 0:
+        out = np.zeros(rows)
+        np.add.at(out, row_of, xv.astype(np.float64) * va.astype(np.float64))
+        return out.astype(np.float32)
+    out = np.zeros(rows, np.int64)
+    np.add.at(out, row_of, ((xv != 0) & (va != 0)).astype(np.int64))
+    return (out > 0).astype(np.int32)
+
+
+def random_matrix(rng, rows, cols, avg, heavy=0, hlen=3000, oob=False, local=False):
+    deg = rng.poisson(avg, rows).astype(np.int64)
+    deg[rng.integers(0, rows, max(1, rows // 10))] = 0                     # empty rows
+    for h in rng.integers(0, rows, heavy):
+        deg[h] = hlen + rng.integers(0, 500)                               # heavy rows (>= 512 entries and >= 8 per tile)
+    for h in rng.integers(0, rows, max(1, rows // 50)):
+        deg[h] = rng.integers(30, 400)                                     # medium rows: many entries per (row, tile)
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, cols, nnz).astype(np.int32)
+    if local:
+        ci = ((np.repeat(np.arange(rows), deg) * (cols / rows)).astype(np.int64) + rng.integers(-50, 50, nnz)).clip(0, cols - 1).astype(np.int32)
+    if oob and nnz:
+        ci[rng.integers(0, nnz, max(1, nnz // 100))] = rng.choice([-1, cols, cols + 5, 2 ** 31 - 1])
+    va = rng.integers(1, 17, nnz).astype(np.float32)
+    return rp, ci, va
+
+
+SHAPES = [  # rows, cols, avg degree, heavy rows, extra
+    (3000, 3000, 8, 2, {}), (3000, 100_000, 12, 3, {}), (20_000, 200_000, 10, 4, {}), (500, 70_000, 40, 5, dict(hlen=9000)),
+    (3000, 100_000, 12, 3, dict(oob=True)), (8000, 40_000, 15, 0, dict(local=True)), (100, 33_000, 3, 0, {}), (1, 5, 3, 0, {}),
+    (40_000, 1_000_000, 14, 6, dict(hlen=20_000)),
+]
+OPTIONS = [dict(fold=1), dict(fold=0), dict(fold=1, value_coding=-1), dict(fold=1, value_coding=8), dict(fold=1, chunk=2048)]
+
+
+@pytest.mark.parametrize("shape", range(len(SHAPES)))
+def test_emulated_plan_equals_csr_product(emu, shape):
+    rows, cols, avg, heavy, kw = SHAPES[shape]
+    rng = np.random.default_rng(100 + shape)
+    rp, ci, va = random_matrix(rng, rows, cols, avg, heavy, **kw)
+    for sem in (0, 2):
+        vals = va if sem == 0 else va.astype(np.int32)
+        for options in OPTIONS:
+            rc, y, st, x = emulate(emu, rows, cols, rp, ci, vals, sem, **options)
+            assert rc == 0, (rc, options, st)
+            assert st["poison_reads"] == 0, (options, st)            # every word phase 2 read had been written by phase 1
+            np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, vals, x, sem), err_msg=str((sem, options, st)))
+            if options.get("fold") == 0:
+                assert st["products"] >= st["light"]                  # one product per light entry (+ padding)
+
+
+def test_folding_removes_the_duplicates_of_a_row_inside_a_tile(emu):
+    """A matrix whose rows keep their columns within one tile: with folding a row of d entries travels through P as
+    ceil(d / 4) products (+ padding), without as d."""
+    rng = np.random.default_rng(7)
+    rows, cols = 5000, 30_000          # one column tile
+    deg = rng.integers(1, 33, rows).astype(np.int64)
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, cols, int(rp[-1])).astype(np.int32)
+    va = rng.integers(1, 17, int(rp[-1])).astype(np.float32)
+    rc, y, st, x = emulate(emu, rows, cols, rp, ci, va, 0, fold=1)
+    assert rc == 0 and st["poison_reads"] == 0
+    np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, va, x, 0))
+    want = int(np.ceil(deg / 4).sum())
+    assert want <= st["products"] <= want + 4 * st["bins"] * st["tiles"]
+    rc, y0, st0, _ = emulate(emu, rows, cols, rp, ci, va, 0, fold=0)
+    assert rc == 0 and st0["products"] >= int(deg.sum())
+    np.testing.assert_array_equal(y0, y)

@@ -1,11 +1,12 @@
 #!/bin/bash
 # tools/kstats_cmd.sh <outdir> <python script> [args] -- rocprofv3 kernel-trace stats of any script in this repo
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
-mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 script=$GRAFT_REPO_ROOT/$1; shift
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $script "$@" > $out/stdout.txt 2> $out/err.log
 python3 - $out <<'PY'
 import csv, glob, sys
-for r in csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0])):
+import os
+for r in csv.DictReader(open(max(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"), key=os.path.getmtime))):
     print(f"{r['Name'][:48]:48s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:10.1f}")
 PY

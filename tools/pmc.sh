@@ -4,12 +4,12 @@
 # Writes <outdir>/traffic.json: one record {workload, layout, n_gpus, bytes, ...} for profiles/measured_traffic.json
 # (bench.py echoes it as roofline.traffic only for exactly that workload and device layout).
 name=$1; out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
-mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp   # a fresh directory per run
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ablation "$@" > $out/$ctr.json 2> $out/$ctr.err
 done
 python3 - $out $name <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out, name = sys.argv[1], sys.argv[2]
 tot = {}
 per = {}
@@ -18,7 +18,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     if not f:
         print(ctr, "no counter file", glob.glob(f"{out}/{ctr}/*/*")); continue
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         if r["Counter_Name"] == ctr and "spmv" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
     for k, v in acc.items():

@@ -300,11 +300,14 @@ static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t>
 
 // ---- x-tiled two-phase plan (see kernels.hip.h) ---------------------------
 // Host-side layout construction.  The tile-major stream is a partition of the light entries by
-// column tile and, inside a tile, by row bin; inside a (bin, tile) piece the entries of one row
-// form a RUN (at most 4 entries; longer ones are cut) that phase 1 folds into ONE product, and
-// runs are packed into whole groups of 4 entries (one lane of phase 1) so that no run straddles
-// a group.  Every piece is a whole number of groups and yields a multiple of 4 products, so a
-// piece starts 16-byte aligned in P.
+// column tile and, inside a tile, by row bin.  A lane of phase 1 owns a GROUP of 4 consecutive stream
+// entries and stores their 4 products with one 16-byte store.  Two entries of one row that fall
+// into the same (bin, tile) piece form a PAIR that phase 1 folds into ONE product: pairs are laid
+// out column-wise over two consecutive groups A, B (entry k of B pairs with entry k of A; A sits at
+// an even group index of the tile's run, so the two lanes are the two halves of a lane pair): lane A
+// adds B's products to its own (one DPP move each) and stores 4 products, lane B stores nothing.  A
+// piece is a whole number of groups and yields a multiple of 4 products, so it starts 16-byte
+// aligned in P.
 struct TiledHost {
   std::vector<RowBin> bins;
   std::vector<TileChunk> chunks;
@@ -322,21 +325,17 @@ struct TiledHost {
   double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
 };
 
-// How the runs of one (bin, tile) piece -- n4 of 4 entries, n3 of 3, n2 of 2, n1 singles -- pack into groups of 4
-// entries: a 4 alone, a 3 with a single (while there are any), 2s in pairs (an odd one with up to two singles),
-// the other singles four to a group.  Free positions are padding entries; a padding entry either joins the run
-// in front of it (no product of its own) or is a run of its own (a padding product): as many of them as bring the
-// piece's products to a multiple of 4, in one more group if the free positions do not suffice.
-struct PiecePack { int32_t groups, products; };
-static PiecePack pack_piece(int64_t n4, int64_t n3, int64_t n2, int64_t n1) {
-  int64_t s = n1, G = n4 + n3;
-  s -= std::min(n3, s);
-  G += n2 / 2;
-  if (n2 & 1) { G++; s -= std::min<int64_t>(s, 2); }
-  G += (s + 3) / 4;
-  const int64_t E = 4 * n4 + 3 * n3 + 2 * n2 + n1, R = n4 + n3 + n2 + n1, need = (-R) & 3;
-  if (need > 4 * G - E) G++;
-  return PiecePack{(int32_t)G, (int32_t)(R + need)};
+// How one (bin, tile) piece with np pairs and ns single entries is laid out: pair blocks of two groups (4 pairs
+// each; columns without a pair take a single in A and a padding entry in B), then the remaining singles four to a
+// group (padding entries = padding products at the end).  A piece with pair blocks always has a singles group --
+// all padding if need be -- that the builder puts in FRONT when the piece starts at an odd group index, so that
+// every A lands on an even one.
+struct PiecePack { int32_t blocks, sgroups, groups, products; };
+static PiecePack pack_piece(int64_t np, int64_t ns) {
+  const int64_t blocks = (np + 3) / 4, spare = 4 * blocks - np;
+  int64_t sg = (std::max<int64_t>(0, ns - spare) + 3) / 4;
+  if (blocks > 0 && sg == 0) sg = 1;
+  return PiecePack{(int32_t)blocks, (int32_t)sg, (int32_t)(2 * blocks + sg), (int32_t)(4 * (blocks + sg))};
 }
 
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
@@ -361,12 +360,12 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     std::vector<int32_t> start;                     // per touched tile: first entry in s_*
     std::vector<uint16_t> rt;                       // tiles of one row (products per row)
     std::vector<int32_t> row_next;                  // per row of the bin: next product index inside the row
-    std::vector<int32_t> l4, l3, l2, l1;            // runs of a piece by length (index of the first entry in s_*)
+    std::vector<int32_t> lp, ls;                    // pairs / singles of a piece (index of the first entry in s_*)
   };
   std::vector<Scratch> scratch((size_t)NT);
   for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
 
-  // 1. products per light row (= its length without folding; with folding sum over tiles of ceil(entries in the tile / 4)),
+  // 1. products per light row (= its length without folding; with folding sum over tiles of ceil(entries in the tile / 2)),
   //    light row offsets in products (heavy rows have light length 0 and carry bit 31) and row bins
   H.lrp.assign((size_t)rows + 1, 0u);
   {
@@ -384,7 +383,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         for (size_t i = 0; i < sc.rt.size();) {
           size_t k = i + 1;
           while (k < sc.rt.size() && sc.rt[k] == sc.rt[i]) k++;
-          n += (int32_t)((k - i + 3) / 4);
+          n += (int32_t)((k - i + 1) / 2);
           i = k;
         }
         nprod[(size_t)r] = n;
@@ -464,14 +463,12 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     }
     for (int t : sc.touched) sc.count[(size_t)t] = 0;   // scratch back to all-zero
   };
-  // the runs of the entries [a, e) of sc.s_* (one tile): same row, at most 4 entries (1 without folding), by length
+  // the entries [a, e) of sc.s_* (one tile) as pairs (two consecutive entries of one row; none without folding) and singles
   auto find_runs = [&](Scratch &sc, int32_t a, int32_t e) {
-    sc.l4.clear(); sc.l3.clear(); sc.l2.clear(); sc.l1.clear();
+    sc.lp.clear(); sc.ls.clear();
     for (int32_t i = a; i < e;) {
-      int32_t k = i + 1;
-      if (fold) while (k < e && k - i < 4 && sc.s_row[(size_t)k] == sc.s_row[(size_t)i]) k++;
-      (k - i == 4 ? sc.l4 : k - i == 3 ? sc.l3 : k - i == 2 ? sc.l2 : sc.l1).push_back(i);
-      i = k;
+      if (fold && i + 1 < e && sc.s_row[(size_t)i + 1] == sc.s_row[(size_t)i]) { sc.lp.push_back(i); i += 2; }
+      else { sc.ls.push_back(i); i += 1; }
     }
   };
   // P1
@@ -485,7 +482,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     int64_t n = 0;
     for (size_t k = 0; k < sc.touched.size(); k++) {
       find_runs(sc, sc.start[k], sc.start[k + 1]);
-      const PiecePack pk = pack_piece((int64_t)sc.l4.size(), (int64_t)sc.l3.size(), (int64_t)sc.l2.size(), (int64_t)sc.l1.size());
+      const PiecePack pk = pack_piece((int64_t)sc.lp.size(), (int64_t)sc.ls.size());
       out.push_back(Piece{sc.touched[k], sc.start[k + 1] - sc.start[k], pk.groups, pk.products, 0, 0, 0});
       n += pk.products;
     }
@@ -664,52 +661,46 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         rec[(g_in_bin % 64) / 32] |= 1u << (g_in_bin % 32);
       }
       find_runs(sc, sc.start[(size_t)piece_k], sc.start[(size_t)piece_k + 1]);
-      // Lay the runs out group by group.  q: next stream position; o: next product of the piece.  A run of len entries
-      // at s_*[i..] gets fold flags on all but its last entry; free positions behind it in the same group are padding
-      // entries that either join it (flag on the entry in front) or -- the first `need` of them -- are padding products.
+      // Lay the piece out (see pack_piece): q = next stream position, o = next product of the piece.  Products are
+      // numbered in stream order of the groups that store (A groups and singles groups).
       int64_t q = spos, o = 0;
-      const int64_t R = (int64_t)(sc.l4.size() + sc.l3.size() + sc.l2.size() + sc.l1.size());
-      int64_t need = (-R) & 3;
-      auto put_run = [&](int32_t i, int len) {
+      const PiecePack pk = pack_piece((int64_t)sc.lp.size(), (int64_t)sc.ls.size());
+      auto slot_of = [&](int32_t i) -> uint16_t {   // the next free product slot of the row of entry s_*[i]
         const int32_t rl = sc.s_row[(size_t)i];
-        for (int k = 0; k < len; k++) {
-          put_entry(q, sc.s_j[(size_t)i + k]);
-          if (k + 1 < len) H.tcol[(size_t)q] |= TCOL_FOLD;
-          q++;
-        }
-        const int64_t slot0 = light_off((int64_t)b.r0 + rl) - b.csr0;
-        H.pslot[(size_t)(off + o)] = (uint16_t)(slot0 + sc.row_next[(size_t)rl]++);
-        o++;
-      };
-      auto pad_to_group_end = [&]() {   // q is inside a group (or at its end): fill up with padding entries
-        while (q & 3) {
-          if (need > 0) { need--; o++; }               // a padding product of its own (slot stays TSLOT_PAD)
-          else H.tcol[(size_t)q - 1] |= TCOL_FOLD;     // joins the run in front of it
-          q++;
-        }
+        return (uint16_t)(light_off((int64_t)b.r0 + rl) - b.csr0 + sc.row_next[(size_t)rl]++);
       };
       size_t s1 = 0;   // singles handed out so far
-      for (int32_t i : sc.l4) put_run(i, 4);
-      for (int32_t i : sc.l3) { put_run(i, 3); if (s1 < sc.l1.size()) put_run(sc.l1[s1++], 1); else pad_to_group_end(); }
-      for (size_t k = 0; k + 1 < sc.l2.size(); k += 2) { put_run(sc.l2[k], 2); put_run(sc.l2[k + 1], 2); }
-      if (sc.l2.size() & 1) {
-        put_run(sc.l2.back(), 2);
-        for (int k = 0; k < 2 && s1 < sc.l1.size(); k++) put_run(sc.l1[s1++], 1);
-        pad_to_group_end();
-      }
-      while (s1 < sc.l1.size()) {
-        put_run(sc.l1[s1++], 1);
-        if ((q & 3) == 0) continue;
-        if (s1 == sc.l1.size()) pad_to_group_end();
-      }
-      if (need > 0) {   // one more group: `need` padding products (the last one made of the remaining entries)
+      auto singles_group = [&]() {   // up to 4 singles; the rest of the group stays padding (identity column, slot TSLOT_PAD)
+        for (int k = 0; k < 4; k++)
+          if (s1 < sc.ls.size()) {
+            const int32_t i = sc.ls[s1++];
+            put_entry(q + k, sc.s_j[(size_t)i]);
+            H.pslot[(size_t)(off + o + k)] = slot_of(i);
+          }
+        q += 4; o += 4;
+      };
+      int32_t sg_left = pk.sgroups;
+      if (pk.blocks > 0 && ((q / 4) & 1)) { singles_group(); sg_left--; }   // pair blocks start on even group indices
+      for (int32_t blk = 0; blk < pk.blocks; blk++) {
         for (int k = 0; k < 4; k++) {
-          if (need > 0) { need--; o++; }
-          else H.tcol[(size_t)q - 1] |= TCOL_FOLD;
-          q++;
+          const size_t pi = (size_t)blk * 4 + (size_t)k;
+          if (pi < sc.lp.size()) {                       // a pair: first entry in A, second in B
+            const int32_t i = sc.lp[pi];
+            put_entry(q + k, sc.s_j[(size_t)i]);
+            put_entry(q + 4 + k, sc.s_j[(size_t)i + 1]);
+            H.pslot[(size_t)(off + o + k)] = slot_of(i);
+          } else if (s1 < sc.ls.size()) {                // a single in A; B keeps its padding entry
+            const int32_t i = sc.ls[s1++];
+            put_entry(q + k, sc.s_j[(size_t)i]);
+            H.pslot[(size_t)(off + o + k)] = slot_of(i);
+          }
         }
+        H.tcol[(size_t)q + 4] |= TCOL_FOLD;              // group B folds into the lane in front of it
+        q += 8; o += 4;
       }
-      // (the layout above must agree with pack_piece(): sizes were fixed from it)
+      while (sg_left-- > 0) singles_group();
+      if (s1 != sc.ls.size()) ok = false;
+      // (the layout above must agree with the sizes fixed in the first pass)
       if (q - spos != 4ll * pc.groups || o != pc.prods) ok = false;
       off += pc.prods;
       piece_k++;
@@ -745,18 +736,18 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int32_t j = rp[r]; j < rp[r + 1]; j++)
       put_entry(sc.pos[(size_t)tile_of(ci[j])]++, j);
   });
-  // P6: obase[block] = P position of the first product of the block's 64 stream groups (a group yields one product
-  // per entry WITHOUT a fold flag).  Read back from the flags just written, so the two cannot disagree; a tile's
-  // run ends in padding groups (run starts are multiples of 64 groups) whose products nobody reads.
+  // P6: obase[block] = P position of the first product of the block's 64 stream groups (a group stores 4 products
+  // unless its first entry carries the fold flag).  Read back from the flags just written, so the two cannot disagree.
   std::vector<int64_t> ob0((size_t)CT + 1, 0);
   for (int t = 0; t < CT; t++) ob0[(size_t)t + 1] = ob0[(size_t)t] + (((run_len[(size_t)t] + 255) & ~int64_t(255)) / 256);
   H.obase.assign((size_t)ob0[(size_t)CT] + 1, 0u);
   parallel_items(CT, 1, NT, [&](int64_t t, int) {
     int64_t pp = run_pstart[(size_t)t];
     const int64_t s0 = run_start[(size_t)t], s1 = s0 + run_len[(size_t)t];
-    for (int64_t q = s0; q < s1; q++) {
+    for (int64_t q = s0; q < s1; q += 4) {
       if (((q - s0) & 255) == 0) H.obase[(size_t)(ob0[(size_t)t] + (q - s0) / 256)] = (uint32_t)pp;
-      if (!(H.tcol[(size_t)q] & TCOL_FOLD)) pp++;
+      if (!(H.tcol[(size_t)q] & TCOL_FOLD)) pp += 4;
+      else if (((q - s0) & 255) == 0) ok = false;   // a pair never straddles a block of 64 groups
     }
     if (pp != run_pstart[(size_t)t] + run_plen[(size_t)t]) ok = false;
   });
@@ -1511,25 +1502,26 @@ int emulate(const TiledHost &H, int64_t rows, int64_t cols, const uint32_t *x, u
     for (int i = 0; i < TCOLS; i++) xs[(size_t)i] = (c0 + i < cols) ? x[c0 + i] : tobits<T>(SR::identity());
     xs[(size_t)TCOLS] = tobits<T>(SR::identity());
     auto prod = [&](int64_t q, uint32_t colmask) { return SR::mul(hbits<T>(xs[H.tcol[(size_t)q] & colmask]), hbits<T>(value_at(q))); };
-    if (ch.hs > ch.s) {   // light chunk: blocks of 64 groups, compacted products
+    if (ch.hs > ch.s) {   // light chunk: blocks of 64 groups; a group stores 4 products unless it folds into the one in front
       if (ch.s % 256 || ch.e % 4) return -10;
       const int64_t gs = ch.s / 4, le = ch.e / 4;
+      auto flagged = [&](int64_t g) { return g < le && (H.tcol[(size_t)g * 4] & TCOL_FOLD) != 0; };
       for (int64_t blk = 0; gs + blk * 64 < le; blk++) {
         int64_t pos = H.obase[(size_t)ch.ob0 + (size_t)blk];
         for (int64_t g = gs + blk * 64; g < std::min(le, gs + blk * 64 + 64); g++) {
-          T acc = SR::identity();
-          bool open = false;
-          for (int k = 0; k < 4; k++) {
-            const int64_t q = g * 4 + k;
-            const T p = prod(q, 0x7FFFu);
-            acc = open ? SR::add(acc, p) : p;
-            open = (H.tcol[(size_t)q] & TCOL_FOLD) != 0;
-            if (!open) {
-              if (pos >= H.p_len) return -11;
-              P[(size_t)pos++] = tobits<T>(acc);
-            }
+          const int64_t lane = g - (gs + blk * 64);
+          if (flagged(g)) {
+            if (!(lane & 1)) return -12;   // a B group sits on an odd lane, right behind its A
+            continue;
           }
-          if (open) return -12;   // a run must end inside its group
+          const bool takes = (lane & 1) == 0 && lane + 1 < 64 && flagged(g + 1);
+          if (pos + 4 > H.p_len) return -11;
+          for (int k = 0; k < 4; k++) {
+            T acc = prod(g * 4 + k, k == 0 ? 0x7FFFu : 0xFFFFu);
+            if (takes) acc = SR::add(acc, prod((g + 1) * 4 + k, k == 0 ? 0x7FFFu : 0xFFFFu));
+            P[(size_t)pos + k] = tobits<T>(acc);
+          }
+          pos += 4;
         }
       }
     } else {              // heavy chunk: strips of 16, segmented scan inside waves of 64 strips

@@ -454,14 +454,10 @@ constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 #ifndef SH_P1_UNROLL
 #define SH_P1_UNROLL 2
 #endif
-#ifndef SH_P1_STORE
-#define SH_P1_STORE 2   // how phase 1 writes its compacted products: 0 dword stores, 1 one 1..4-dword store per lane, 2 via LDS as 16-byte stores
-#endif
-constexpr int P1_STG = 272;             // words of the LDS staging strip of one wave (256 products + alignment shift, padded)
 constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
 constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
-constexpr uint16_t TCOL_FOLD = 0x8000;     // light entries: this entry's product is folded into the next entry's (same row, same tile)
+constexpr uint16_t TCOL_FOLD = 0x8000;     // on the FIRST column code of a light group: the group's 4 products are folded into those of the group (lane) in front
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
 static_assert(TCOLS % 8 == 0 && TCOLS < 32768 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile; bit 15 is the fold flag");
 // Heavy rows: every (row, tile) piece is padded to whole STRIPS of HSTRIP consecutive stream entries.  One
@@ -532,7 +528,7 @@ struct NoHook { __device__ void operator()() const {} };
 // staged(): called by every thread right after the barrier that publishes the x tile (SH_STATS builds stamp it).
 template <class SR, int VC, class Hook = NoHook>
 __device__ __forceinline__ void tiled_phase1_chunk(
-    const TileChunk ch, uint32_t *xs, uint32_t *ds, uint32_t *stg_all, const void *__restrict__ tval_or_code,
+    const TileChunk ch, uint32_t *xs, uint32_t *ds, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
     uint32_t *__restrict__ P, uint32_t *__restrict__ partial, Hook staged = NoHook()) {
@@ -584,30 +580,35 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       v = make_uint4(ds[w & 0xFu], ds[(w >> 4) & 0xFu], ds[(w >> 8) & 0xFu], ds[(w >> 12) & 0xFu]);
     else
       v = w;
-    // (bit 15 of a column code is the fold flag)
+    // (bit 15 of a group's first column code is the fold flag)
     pr[0] = SR::mul(from_bits<T>(xs[c.x & 0x7FFFu]), from_bits<T>(v.x));
-    pr[1] = SR::mul(from_bits<T>(xs[(c.x >> 16) & 0x7FFFu]), from_bits<T>(v.y));
-    pr[2] = SR::mul(from_bits<T>(xs[c.y & 0x7FFFu]), from_bits<T>(v.z));
-    pr[3] = SR::mul(from_bits<T>(xs[(c.y >> 16) & 0x7FFFu]), from_bits<T>(v.w));
+    pr[1] = SR::mul(from_bits<T>(xs[c.x >> 16]), from_bits<T>(v.y));
+    pr[2] = SR::mul(from_bits<T>(xs[c.y & 0xFFFFu]), from_bits<T>(v.z));
+    pr[3] = SR::mul(from_bits<T>(xs[c.y >> 16]), from_bits<T>(v.w));
   };
   // Both loops are software-pipelined: the loads of batch i+1 are issued before batch i is
   // consumed, so a wave always has one batch of loads in flight behind the stores it issues
   // (stores count in vmcnt on gfx9: without this every batch would wait out the previous
   // batch's write latency).  Loads are unconditional on clamped indices -- one basic block.
-  // ---- light entries.  A lane owns a group of 4 consecutive stream entries.  Entries of one row that fall into
-  // this tile lie next to each other inside a group (the plan packs them so) and carry the FOLD flag on all
-  // but the last: their products are summed here, in stream order, and only the sum travels through P --
-  // a fifth of the light products of a power-law matrix never leave the lane.  A group therefore yields 1..4
-  // products; they are stored compacted: the product count of the lanes below comes from three ballots, the P
-  // position of the wave's first product from obase[] (one scalar load per 64 groups; the plan builder counted
-  // the flags), so the wave's products form one contiguous run of P (how it is written: SH_P1_STORE below).
-  // (ping-pong register sets A/B instead of a copy at the loop end: a copy would wait for the
-  // loads it copies)
+  // ---- light entries.  A lane owns a group of 4 consecutive stream entries and stores their 4 products with one
+  // 16-byte store.  Two entries of one row that fall into this tile are a PAIR, laid out column-wise over the two
+  // lanes of a lane pair (entry k of the odd lane B pairs with entry k of the even lane A; B's first column code
+  // carries the FOLD flag): A adds B's four products to its own -- one DPP move each, no LDS -- and B stores nothing,
+  // so a seventh of the light products of a power-law matrix never leave the register file.  Every lane thus stores
+  // 0 or 4 products and the wave's products stay one contiguous, 16-byte aligned run of P: a storing lane's place is
+  // the number of storing lanes below it (one ballot), the wave's place comes from obase[] (one scalar load per 64
+  // groups; the plan builder counted the flags).
+  // (Measured on the way here, same box, profiles/r03_ab_phase1_store_variants.log and r03_kernel_times_store_variants*:
+  // folding runs of up to 4 entries INSIDE a lane leaves 1..4 products per lane; compacting them cost more than the
+  // bytes saved -- four predicated dword stores per lane +93 us per SpMV, one 1..4-dword store per lane +55 us of
+  // phase 1, through a wave-private LDS strip as 16-byte stores +32..36 us of phase 1 -- while phase 2 gained 37 us.)
+  // Software-pipelined: the loads of batch i+1 are issued before batch i is consumed (ping-pong register sets A/B
+  // instead of a copy at the loop end: a copy would wait for the loads it copies).
   // A chunk is either all light (hs == e) or all heavy (hs <= s): the plan builder cuts them apart.
   const int le = min(ch.e, max(ch.s, ch.hs)) / 4;
   if (ch.hs > ch.s) {
     constexpr int S = TBS * U;
-    const int gs = ch.s / 4, last_blk = (le - gs - 1) >> 6;
+    const int gs = ch.s / 4, last_blk = (le - gs - 1) >> 6, lane = tid & 63;
     auto load = [&](int gbase, VWord (&vw)[U], uint2 (&c)[U], uint32_t (&ob)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
@@ -618,9 +619,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
         ob[k] = obase[ch.ob0 + __builtin_amdgcn_readfirstlane(min((gbase + k * TBS - gs) >> 6, last_blk))];
       }
     };
-    // (the loop runs per WAVE: a wave goes on while its first group is inside the chunk, lanes past the end carry no
-    // products -- the store stage below hands quads of the wave's strip to lanes whether or not they had a group)
-    const int lane = tid & 63;
+    // (the loop runs per WAVE -- while the wave's first group is inside the chunk -- so that every lane takes part in
+    // the DPP moves and ballots; lanes past the end of the chunk neither fold nor store)
     auto consume = [&](int gbase, const VWord (&vw)[U], const uint2 (&c)[U], const uint32_t (&ob)[U]) {
 #pragma unroll
       for (int k = 0; k < U; k++) {
@@ -629,67 +629,20 @@ __device__ __forceinline__ void tiled_phase1_chunk(
           const bool valid = g < le;
           T pr[4];
           products(vw[k], c[k], pr);
-          const bool f0 = (c[k].x & 0x8000u) != 0, f1 = (c[k].x & 0x80000000u) != 0, f2 = (c[k].y & 0x8000u) != 0;
-          const T a1 = f0 ? SR::add(pr[0], pr[1]) : pr[1];
-          const T a2 = f1 ? SR::add(a1, pr[2]) : pr[2];
-          const T a3 = f2 ? SR::add(a2, pr[3]) : pr[3];
-          const uint32_t e0 = f0 ? 0u : 1u, e1 = f1 ? 0u : 1u, e2 = f2 ? 0u : 1u, m = e0 + e1 + e2;   // products of this group - 1
-          const uint64_t bv = __ballot(valid), b0 = __ballot(valid && (m & 1u)), b1 = __ballot(valid && (m & 2u));
-          auto below = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
-          const uint32_t pre = below(bv) + below(b0) + 2u * below(b1);   // products of the lanes below
-#if SH_P1_STORE == 0
-          // four predicated dword stores per lane (measured: 4x the store requests of 16-byte stores, +93 us per SpMV)
-          uint32_t *dst = P + (ob[k] + pre);
-          if (valid) {
-            if (e0) dst[0] = to_bits<T>(pr[0]);
-            if (e1) dst[e0] = to_bits<T>(a1);
-            if (e2) dst[e0 + e1] = to_bits<T>(a2);
-            dst[m] = to_bits<T>(a3);
-          }
-#elif SH_P1_STORE == 1
-          // the lane's products compacted in registers, then ONE store of 1..4 dwords per lane
-          const uint32_t c0 = to_bits<T>(pr[0]), c1 = to_bits<T>(a1), c2 = to_bits<T>(a2), c3 = to_bits<T>(a3);
-          const uint32_t o0 = e0 ? c0 : (e1 ? c1 : (e2 ? c2 : c3));
-          const uint32_t p1 = e0, p2 = e0 + e1;                       // positions of c1, c2 when emitted; c3 sits at m
-          const uint32_t o1 = (e1 && p1 == 1u) ? c1 : ((e2 && p2 == 1u) ? c2 : c3);
-          const uint32_t o2 = (e2 && p2 == 2u) ? c2 : c3;
-          uint32_t *dst = P + (ob[k] + pre);
-          if (valid) {
-            if (m == 3u) { v4u32 v = {o0, o1, o2, c3}; __builtin_memcpy(dst, &v, 16); }
-            else if (m == 2u) { dst[0] = o0; dst[1] = o1; dst[2] = o2; }
-            else if (m == 1u) { dst[0] = o0; dst[1] = o1; }
-            else dst[0] = o0;
-          }
-#else
-          // Compaction through a wave-private strip of LDS, then full 16-byte stores: the wave's products land in
-          // stg[] at the position they have in P modulo 4 (sh = P position of the wave's first product mod 4), lane L
-          // then owns the aligned quad L of the strip: one ds_read_b128 + one 16-byte store; the (at most two) partial
-          // quads at the ends of the wave's run go out as dword stores.  One wave's LDS traffic is served in issue order:
-          // the reads see the writes in front of them and the next group's writes come behind these reads -- no barrier.
-          uint32_t *stg = stg_all + (tid >> 6) * P1_STG;
-          const uint32_t sh = ob[k] & 3u;
-          const uint32_t T1 = (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);   // the wave's products
-          uint32_t *w = stg + sh + pre;
-          if (valid) {
-            if (e0) w[0] = to_bits<T>(pr[0]);
-            if (e1) w[e0] = to_bits<T>(a1);
-            if (e2) w[e0 + e1] = to_bits<T>(a2);
-            w[m] = to_bits<T>(a3);
-          }
-          const uint32_t end = sh + T1;
-          uint32_t *pb = P + (ob[k] - sh);                               // P address of stg[0]: a multiple of 4 products
-          auto put_quad = [&](uint32_t lo) {
-            if (lo >= sh && lo + 4u <= end) {
-              *reinterpret_cast<uint4 *>(pb + lo) = *reinterpret_cast<const uint4 *>(stg + lo);
-            } else if (lo < end && lo + 4u > sh) {
+          const bool folds = valid && (c[k].x & 0x8000u) != 0;          // this lane is the B of a pair
+          const uint64_t fm = __ballot(folds), sm = __ballot(valid && !folds);
+          const bool takes = ((fm >> 1) >> lane) & 1u;                   // the lane behind folds into this one
 #pragma unroll
-              for (uint32_t i = 0; i < 4u; i++)
-                if (lo + i >= sh && lo + i < end) pb[lo + i] = stg[lo + i];
-            }
-          };
-          put_quad(4u * (uint32_t)lane);                                 // quads 0..63 by lane
-          if (end > 256u && lane == 0) put_quad(256u);                   // quad 64: at most 3 products
-#endif
+          for (int i = 0; i < 4; i++) {
+            // quad_perm [1,1,3,3]: an even lane reads its odd neighbour
+            const T up = from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(0, (int)to_bits<T>(pr[i]), 0xF5, 0xF, 0xF, false));
+            if (takes) pr[i] = SR::add(pr[i], up);
+          }
+          if (valid && !folds) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+            *reinterpret_cast<uint4 *>(P + ob[k] + 4u * rank) =
+                make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+          }
         }
       }
     };
@@ -787,14 +740,13 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate) {
   __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC ? VDICT : 1];
-  __shared__ __attribute__((aligned(16))) uint32_t stg[SH_P1_STORE == 2 ? (TBS / 64) * P1_STG : 4];
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e || (gate != nullptr && *gate == 0))
     return;   // filler that keeps the XCD-aligned chunk order / the iteration loop is over (StepDev::gate)
   SH_STAT(const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime(); __shared__ uint64_t st_staged;)
   SH_STAT(auto stamp = [&]() { if (threadIdx.x == 0) st_staged = __builtin_amdgcn_s_memrealtime(); };)
 #ifdef SH_STATS
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, stg, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, stamp);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, stamp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && g_p1_stats) {   // per chunk: kind, entries, start, staged, end (100 MHz ticks)
@@ -802,7 +754,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     S[0] = ch.hs <= ch.s; S[1] = (uint64_t)(ch.e - ch.s); S[2] = st_t0; S[3] = st_staged; S[4] = __builtin_amdgcn_s_memrealtime();
   }
 #else
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, stg, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial);
 #endif
 }
 

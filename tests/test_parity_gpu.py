@@ -685,7 +685,7 @@ def test_folded_runs_match_oracle(eng, plan, sr):
     assert (" folded" in A.describe()) == folded, A.describe()
     light = float(A.describe().split("light=")[1].split("M")[0])
     prods = float(A.describe().split("products=")[1].split("M")[0])
-    assert (prods < 0.6 * light) if folded else (prods >= light), A.describe()
+    assert (prods < 0.62 * light) if folded else (prods >= light), A.describe()
     rng = np.random.default_rng(9)
     out = eng.alloc(n).fill(0)
     a, b = {O.PLUS_TIMES_F32: (2.0, 0.5), O.MIN_PLUS_F32: (1.0, 2.0), O.OR_AND_I32: (1, 1), O.MAX_MIN_I32: (700, -300)}[sr]

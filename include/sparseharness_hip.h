@@ -125,6 +125,11 @@ typedef struct sh_plan_options {
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
+/* Prefix sum (rows + 1 values, work_prefix[0] = 0) of the HBM bytes the engine expects to move per row under the
+ * plan it would choose for a matrix of these dimensions: what row-range sharding across GPUs balances on (the
+ * reference has one device, inc/harness.h:419).  Host-only: needs no device.  opt == NULL: the defaults. */
+int sh_plan_row_work(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const sh_plan_options *opt,
+                     uint64_t *work_prefix);
 int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
                      const int32_t *row_ptr, const int32_t *col_idx, const void *val,
                      const sh_plan_options *opt, sh_csr **out);
@@ -197,6 +202,26 @@ int sh_spmv(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x,
  *      (TODO.md:7-8).  ns_per_iter (may be NULL, capacity max_iters) receives
  *      each launch's device time; total_ns their sum (MULTI_ITERATION_SUM,
  *      app/sssp.cpp:77-84). */
+/* The same step for a matrix whose rows live in PIECES of the vectors (multi-GPU iteration driver: the vectors
+ * interleave the pieces of all ranks so that piece c of every rank is one contiguous region to all-gather; the
+ * reference has one device and no counterpart, app/sssp.cpp:112-153 is the loop this serves).  Row r belongs to
+ * piece c = r / piece_rows and is element element_of_piece[c] + (r - c * piece_rows) of out, of y and -- for the
+ * convergence test -- of x.  With report != 0 the launch tells when each piece is complete: *done_words then points
+ * to n_pieces words in host memory (owned by the matrix) and word c reaches *round once every row of piece c is
+ * written and visible system-wide, pieces completing in ascending order while the launch is still running, so the
+ * caller can start exchanging piece c while later pieces are being computed.  ONE launch of the ordinary plan: no
+ * per-piece matrices.  At most 8 pieces. */
+typedef struct sh_row_pieces {
+  int32_t n_pieces;
+  int32_t piece_rows;
+  int64_t element_of_piece[8];
+  int32_t report;
+  int32_t reserved;
+} sh_row_pieces;
+int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x, const sh_vec *y,
+                        const void *alpha, const void *beta, sh_vec *out, const sh_row_pieces *pieces, double delta,
+                        int32_t *changed_flag_device, uint32_t *round, const volatile uint32_t **done_words);
+
 int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x,
                const sh_vec *y0, sh_vec *scratch, const void *alpha,
                const void *beta, double delta, int32_t max_iters,

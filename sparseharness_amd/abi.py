@@ -28,6 +28,12 @@ class sh_plan_options(C.Structure):
                 ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32)]
 
 
+class sh_row_pieces(C.Structure):
+    """Row pieces of sh_spmv_step_pieces (include/sparseharness_hip.h)."""
+    _fields_ = [("n_pieces", C.c_int32), ("piece_rows", C.c_int32), ("element_of_piece", C.c_int64 * 8),
+                ("report", C.c_int32), ("reserved", C.c_int32)]
+
+
 _vp, _i32, _i64, _u64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
 _pp = C.POINTER(C.c_void_p)
 
@@ -46,6 +52,7 @@ SIGNATURES = {
     "sh_csr_upload": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),
     "sh_plan_options_default": (None, [C.POINTER(sh_plan_options)]),
     "sh_plan_options_from_env": (None, [C.POINTER(sh_plan_options)]),
+    "sh_plan_row_work": (_int, [_i64, _i64, _i64, _vp, C.POINTER(sh_plan_options), _vp]),
     "sh_csr_upload_ex": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(sh_plan_options), _pp]),
     "sh_csr_free": (_int, [_vp, _vp]),
     "sh_csr_dims": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -67,6 +74,8 @@ SIGNATURES = {
                           C.POINTER(sh_launch), C.POINTER(_i32), C.POINTER(_i32),
                           C.POINTER(_u64), C.POINTER(_u64)]),
     "sh_spmv_step": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_double, _vp]),
+    "sh_spmv_step_pieces": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(sh_row_pieces), C.c_double, _vp,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32))]),
 }
 
 _lib = None

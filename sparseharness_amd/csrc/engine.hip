@@ -72,6 +72,9 @@ struct sh_csr {
   int64_t stream_len = 0, p_len = 0;          // stream entries in all / products in P
   int fold = 0;                               // phase 1 folds a row's entries inside a tile into one product
   size_t stream_bytes = 0, tiled_bytes = 0;   // device memory held by the arrays of plan A / plan B
+  std::vector<int32_t> bin_r0;                // first row of every row bin (host copy: piece reporting)
+  uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
+  uint32_t round = 0;                         // reporting launches so far
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
 
@@ -811,6 +814,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   };
   // cut one run into chunks
   std::vector<TileChunk> per_xcd[8];
+  // (Guided sizes -- the first 60..75 % of every run in items of 128..256 K entries, the rest in items a quarter that
+  // size handed out behind all the big ones -- were measured and lost: 0.446..0.454 vs 0.435 ms same box,
+  // profiles/r03_ab_guided_chunk_sizes.log; plain 128 K items: 0.431.)
   auto cut_run = [&](int t, int64_t start, int64_t len, bool heavy) {
     // equal cuts: a run of 56 K entries becomes 2 x 28 K, not 32 K + 24 K (the launch ends with its slowest workgroup)
     const int64_t pieces = (len + chunk - 1) / chunk;
@@ -903,6 +909,31 @@ static int choose_plan(const sh_plan_options &opt, int64_t cols, int64_t nnz) {
   if (opt.plan == 2) return PLAN_TILED;
   // auto: x beyond the per-XCD L2 (4 MiB) makes global gathers line-miss bound
   return (cols > (1 << 20) && nnz >= (1 << 22)) ? PLAN_TILED : PLAN_STREAM;
+}
+
+// Estimated HBM bytes per row under the plan sh_csr_upload would choose, as a prefix sum: what row-range sharding
+// balances on (a shard full of heavy rows would otherwise finish early while the others still stream).  The weights
+// follow the tiled plan's traffic: an entry of a light row ~3 B of stream + ~10.5 B for the product that travels
+// through P (pair folding saves a seventh of them), an entry of a heavy row ~3 B of stream + the padding of its
+// strips; a row costs ~12 B (offsets, result) either way.  CSR-stream plan: 8 B per entry + 12 B per row.
+int sh_plan_row_work(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const sh_plan_options *opt_p,
+                     uint64_t *work_prefix) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !row_ptr || !work_prefix)
+    return SH_EINVAL;
+  sh_plan_options opt;
+  if (opt_p) opt = *opt_p; else sh_plan_options_default(&opt);
+  const bool tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0;
+  const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
+  const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, (int64_t)std::max(1, opt.heavy_per_tile) * CT));
+  uint64_t acc = 0;
+  work_prefix[0] = 0;
+  for (int64_t r = 0; r < rows; r++) {
+    const int64_t d = (int64_t)row_ptr[r + 1] - row_ptr[r];
+    if (d < 0) return SH_ESHAPE;
+    acc += 12u + (uint64_t)(!tiled ? 8 * d : (d >= heavy_thr ? 4 * d : 12 * d));
+    work_prefix[r + 1] = acc;
+  }
+  return SH_OK;
 }
 
 void sh_plan_options_default(sh_plan_options *o) {
@@ -1024,6 +1055,8 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     m->p_len = th.p_len;
     m->light_entries = th.light_entries;
     m->fold = opt.fold != 0;
+    m->bin_r0.reserve(th.bins.size());
+    for (const RowBin &b : th.bins) m->bin_r0.push_back(b.r0);
     DEV_ARRAY(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), 0);
     DEV_ARRAY(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), 0);
     if (!th.vdict.empty()) {
@@ -1073,8 +1106,9 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
                   (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
-                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase})
+                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase, (void *)m->d_done})
     if (p) (void)hipFree(p);
+  if (m->h_done) (void)hipHostFree(m->h_done);
   delete m;
   return SH_OK;
 }
@@ -1309,6 +1343,10 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
+    if (st.done && A->n_bins == 0) {          // nobody reported: one arrival per piece behind everything
+      hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
+      HIP_TRY(e, hipGetLastError());
+    }
     return SH_OK;
   }
   CsrDev dev{A->d_row_ptr, A->d_col, A->d_val, (int32_t)A->rows, (int32_t)A->cols};
@@ -1325,6 +1363,10 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                        e->stream, A->d_long, A->n_long, A->d_partial,
                        use_y ? (const uint32_t *)y->d : nullptr, alpha, beta, use_y ? 1 : 0,
                        (uint32_t *)out->d, st);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (st.done) {   // the CSR-stream kernels do not report pieces: one arrival per piece behind them
+    hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
     HIP_TRY(e, hipGetLastError());
   }
   return SH_OK;
@@ -1392,6 +1434,54 @@ int sh_spmv_step(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x,
   HIP_TRY(e, hipSetDevice(e->device));
   StepDev st{changed_flag_device, (const uint32_t *)x->d, x_row_offset, delta};
   return dispatch(e, sr, A, x, y, alpha, beta, out, st);
+}
+
+int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x, const sh_vec *y,
+                        const void *alpha, const void *beta, sh_vec *out, const sh_row_pieces *pc, double delta,
+                        int32_t *changed_flag_device, uint32_t *round, const volatile uint32_t **done_words) {
+  if (!e || !A || !x || !alpha || !beta || !out || !pc)
+    return fail(e, SH_EINVAL, "sh_spmv_step_pieces: NULL argument");
+  if (pc->n_pieces < 1 || pc->n_pieces > MAX_PIECES || pc->piece_rows < 1 ||
+      (int64_t)pc->piece_rows * pc->n_pieces < A->rows)
+    return fail(e, SH_EINVAL, "sh_spmv_step_pieces: %d pieces of %d rows do not cover %lld rows (at most %d pieces)",
+                pc->n_pieces, pc->piece_rows, (long long)A->rows, MAX_PIECES);
+  if (x->n < A->cols)
+    return fail(e, SH_ESHAPE, "sh_spmv_step_pieces: x has %lld elements, matrix has %lld columns", (long long)x->n, (long long)A->cols);
+  if (out->d == x->d && A->rows > 0)
+    return fail(e, SH_EINVAL, "sh_spmv_step_pieces: out must not alias x");
+  HIP_TRY(e, hipSetDevice(e->device));
+  StepDev st{changed_flag_device, (const uint32_t *)x->d, 0, delta};
+  st.n_pieces = pc->n_pieces;
+  st.piece_rows = pc->piece_rows;
+  for (int c = 0; c < pc->n_pieces; c++) {
+    const int64_t first = (int64_t)c * pc->piece_rows, rows_c = std::max<int64_t>(0, std::min<int64_t>(A->rows - first, pc->piece_rows));
+    const int64_t at = pc->element_of_piece[c];
+    if (at < 0 || at + rows_c > out->n || at + rows_c > x->n || (y && at + rows_c > y->n))
+      return fail(e, SH_ESHAPE, "sh_spmv_step_pieces: piece %d (%lld rows at element %lld) does not fit the vectors", c, (long long)rows_c, (long long)at);
+    st.piece_delta[c] = at - first;
+    // tiled plan: the piece is complete once every bin that starts below its last row + 1 is reduced
+    st.piece_bin_end[c] = (int32_t)(std::lower_bound(A->bin_r0.begin(), A->bin_r0.end(), (int32_t)std::min<int64_t>(first + pc->piece_rows, A->rows)) - A->bin_r0.begin());
+  }
+  if (pc->n_pieces > 0) st.piece_bin_end[pc->n_pieces - 1] = (int32_t)A->bin_r0.size();
+  if (pc->report) {
+    if (!A->d_done) {
+      HIP_TRY(e, hipMalloc((void **)&A->d_done, MAX_PIECES * 4));
+      HIP_TRY(e, hipMemsetAsync(A->d_done, 0, MAX_PIECES * 4, e->stream));
+      HIP_TRY(e, hipHostMalloc((void **)&A->h_done, 64, hipHostMallocDefault));
+      memset(A->h_done, 0, 64);
+    }
+    st.done = A->d_done;
+    st.done_host = A->h_done;
+    // arrivals per piece and launch: one per workgroup of phase 2, or the single one of report_all_pieces
+    st.expected = (A->plan == PLAN_TILED && A->n_bins > 0) ? (uint32_t)std::min(A->n_bins, e->n_cus) : 1u;
+    A->round++;
+    if (round) *round = A->round;
+    if (done_words) *done_words = A->h_done;
+  }
+  // the epilogue reads y through the same row -> element mapping; an epilogue that does not read y gets none
+  sh_vec yfull;
+  if (y) { yfull = *y; yfull.owned = false; yfull.n = std::max<int64_t>(y->n, A->rows); }
+  return dispatch(e, sr, A, x, y ? &yfull : nullptr, alpha, beta, out, st);
 }
 
 int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const sh_vec *y0,

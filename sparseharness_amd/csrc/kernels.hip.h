@@ -52,6 +52,7 @@ struct CsrDev {
 
 // Optional fused convergence test of the iterative apps
 // (should_terminate_iteration, app/sssp.cpp:157-176 / app/bfs.cpp:154-174).
+constexpr int MAX_PIECES = 8;
 struct StepDev {
   int32_t *changed;         // nullptr: no test
   const uint32_t *prev;     // previous vector; row r compares prev[prev_off + r]
@@ -60,7 +61,22 @@ struct StepDev {
   // Launches of an iteration loop are enqueued several iterations ahead of the host (sh_iterate): a launch
   // whose gate word is 0 -- the previous iteration changed nothing, the loop is over -- returns at once.
   const int32_t *gate = nullptr;
+  // Row pieces (multi-GPU iteration driver, sh_spmv_step_pieces): the matrix' rows live in n_pieces runs of piece_rows
+  // rows; row r of piece c = r / piece_rows is element r + piece_delta[c] of out, y and prev (the vectors interleave
+  // the pieces of all ranks so that one piece of every rank is one contiguous region to all-gather).  When a
+  // workgroup has written its last row of piece c it adds 1 to done[c] (after a release at system scope): the
+  // host, polling, then starts the exchange of that piece while the later ones are still being computed.
+  int32_t n_pieces = 0;     // 0: rows are elements 0..rows-1
+  int32_t piece_rows = 0;
+  int64_t piece_delta[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t piece_bin_end[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};   // tiled plan: piece c is complete once every row bin below this index is
+  uint32_t *done = nullptr;       // [n_pieces] arrival counters (device memory, never reset), or nullptr: no reporting
+  uint32_t *done_host = nullptr;  // [n_pieces] words in host memory: the `expected`-th, 2*expected-th, ... arrival at done[c] writes its ordinal / expected
+  uint32_t expected = 0;          // arrivals per piece and launch (= workgroups of the reporting launch)
 };
+__device__ __forceinline__ int64_t row_element(const StepDev &st, int32_t row) {
+  return st.n_pieces ? (int64_t)row + st.piece_delta[min(row / st.piece_rows, st.n_pieces - 1)] : (int64_t)row;
+}
 __device__ __forceinline__ bool gate_closed(const StepDev &st) { return st.gate != nullptr && *st.gate == 0; }
 
 struct LongSeg { int32_t row, s, e, slot; };
@@ -86,13 +102,41 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
                                   typename SR::T alpha, typename SR::T beta, bool use_y,
                                   uint32_t *__restrict__ out, const StepDev &st) {
   using T = typename SR::T;
-  T yv = use_y ? from_bits<T>(y[row]) : SR::identity();
+  const int64_t at = row_element(st, row);
+  T yv = use_y ? from_bits<T>(y[at]) : SR::identity();
   T o = SR::epilogue(dot, alpha, yv, beta, use_y);
-  out[row] = to_bits<T>(o);
+  out[at] = to_bits<T>(o);
   if (st.changed) {
-    T in = from_bits<T>(st.prev[st.prev_off + row]);
+    T in = from_bits<T>(st.prev[st.prev_off + at]);
     if (SR::differs(in, o, st.delta))
       *st.changed = 1;   // benign race: every writer stores 1
+  }
+}
+
+// One workgroup reports "my rows of pieces [c0, c1) are written".  Called by ONE lane after every wave of the
+// workgroup has drained its stores (s_waitcnt vmcnt(0)) and met at a barrier: a release at system scope (the rows
+// are read next by a collective / a copy engine / a peer), then one arrival per piece; the arrival that completes
+// a launch's round tells the host, which polls done_host[c].
+__device__ inline void pieces_done(const StepDev &st, int c0, int c1) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md)
+  for (int c = c0; c < c1; c++) {
+    const uint32_t n = __hip_atomic_fetch_add(st.done + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (n % st.expected == 0u)
+      __hip_atomic_store(st.done_host + c, n / st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// After launches that do not report by themselves (CSR-stream plan, a matrix of heavy rows only): one more tiny
+// launch on the same stream -- every row is written by then -- completes the round of every piece.
+__global__ void report_all_pieces(StepDev st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int c = 0; c < st.n_pieces; c++) {
+      const uint32_t n = __hip_atomic_fetch_add(st.done + c, st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + st.expected;
+      __hip_atomic_store(st.done_host + c, n / st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -831,6 +875,21 @@ __device__ __forceinline__ void tiled_phase2_run(
   // epilogues that read y or the previous vector run as a coalesced pass after one more barrier (MID2)
   const bool staged = use_y || st.changed != nullptr;
   auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * stride]; };   // clamped: scalar loads
+  // Piece reporting (StepDev::done): once this workgroup has reduced j of its bins, every piece whose bins all lie
+  // below its next bin is complete as far as this workgroup is concerned (its heavy rows were written before the
+  // first bin).  Wave-uniform and identical in both roles: all waves drain their stores and meet, one lane reports.
+  int reported = 0;   // pieces [0, reported) reported
+  auto report = [&](int j_done) {
+    if (st.done == nullptr || reported >= st.n_pieces) return;
+    const int next_bin = j_done < nb ? b0 + j_done * stride : 0x7FFFFFFF;
+    int upto = reported;
+    while (upto < st.n_pieces && st.piece_bin_end[upto] <= next_bin) upto++;
+    if (upto == reported) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == P2S_LD) pieces_done(st, reported, upto);
+    reported = upto;
+  };
   if (tid < 8)
     sc.cnt[tid] = 0;
   lds_barrier();
@@ -945,6 +1004,7 @@ __device__ __forceinline__ void tiled_phase2_run(
       if (staged)
         lds_barrier();   // MID2
       lds_barrier();     // END
+      report(j);         // (bins 0 .. j-1 of this workgroup are reduced)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave moves on
   } else {
@@ -994,6 +1054,7 @@ __device__ __forceinline__ void tiled_phase2_run(
           }
       }
       lds_barrier();     // END
+      report(j);
       prev = cur;
     }
   }

@@ -3,25 +3,25 @@ per GPU, the new vector exchanged by all-gather every iteration.
 
 The reference iterates on a single device and copies the whole vector to the
 host every iteration to test convergence (app/sssp.cpp:97-176).  Here each
-rank owns a contiguous, work-balanced row range of the matrix and a full
-replica of x in the layout of partition.SlottedLayout, its rows cut into
-`chunks` pieces:
+rank owns a contiguous, work-balanced row range of the matrix -- ONE device
+matrix, one execution plan -- and a full replica of x in the layout of
+partition.SlottedLayout, in which the rank's rows are cut into `chunks` pieces:
 
     iteration k on rank r:
       1. clear my "changed" word in x_next
-      2. for each chunk c:
-           local step: x_next[piece c of r] = kernel(A_r,c, x_cur, y = x_cur[piece c of r])
-             -- the HIP kernel also raises my changed word (fused convergence test)
-           all_gather_into_tensor(region c of x_next, my piece c), asynchronously
-             -- RCCL over xGMI, in place; it waits for the step just enqueued and runs
-                on the collective's own stream WHILE chunk c + 1 is computed, so only
-                the last chunk's all-gather (1/chunks of the bytes) is exposed
-      3. wait for the all-gathers; every rank now holds every rank's changed word
-         (it travels behind the last chunk): stop when all are 0
-      4. swap x_cur / x_next
+      2. ONE launch of the local step (sh_spmv_step_pieces): x_next[my pieces] = kernel(A_r, x_cur, y = x_cur[my pieces]);
+         the HIP kernel raises my changed word (fused convergence test) and REPORTS every piece the moment its rows
+         are written (a release at system scope + a word in host memory), pieces completing in ascending order
+      3. for each piece c, as soon as it is reported: all_gather_into_tensor(region c of x_next, my piece c),
+         asynchronously on a side stream -- RCCL over xGMI, in place -- WHILE the launch is still computing the later
+         pieces, so only the last piece's all-gather (1/chunks of the bytes, carrying the changed words) is exposed
+      4. wait for the all-gathers; every rank now holds every rank's changed word: stop when all are 0
+      5. swap x_cur / x_next
 
-Step 3 reads `parts` words back to the host (the only PCIe traffic per
-iteration) and waits for exactly that copy.  Results are bit-identical to the
+(Round 2 gave every piece a device matrix of its own -- two launches and a full x-tile staging per piece: +21 % per
+iteration at 4 pieces on one GPU.  One plan with in-launch reporting costs a store drain, a barrier and one release
+per piece and workgroup.)  Step 4 reads `parts` words back to the host (the only PCIe traffic per
+iteration besides the report words) and waits for exactly that copy.  Results are bit-identical to the
 single-GPU sh_iterate for every world size and chunk count, because each row
 is reduced by the same code over the same data.
 
@@ -45,7 +45,8 @@ def _np_dtype(semiring):
 
 
 class ShardPlan:
-    """What one rank needs: its rows of the matrix, cut into `chunks` pieces, columns remapped to layout positions."""
+    """What one rank needs: its rows of the matrix (columns remapped to layout positions) and how they are cut
+    into `chunks` pieces of the vector layout."""
 
     def __init__(self, row_ptr, col_idx, val, rank, world, chunks=1):
         self.rank, self.world = rank, world
@@ -55,30 +56,51 @@ class ShardPlan:
         self.chunks = self.layout.chunks
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.rows = self.r1 - self.r0
-        # per chunk: (row_ptr, col_idx in layout positions, val, rows)
-        self.pieces = []
-        for c in range(self.chunks):
-            lo, n = self.layout.piece_rows(rank, c)
-            rp, ci, va = partition.take_rows(row_ptr, col_idx, val, self.r0 + lo, self.r0 + lo + n)
-            self.pieces.append((np.ascontiguousarray(rp), self.layout.to_slotted_index(ci), np.ascontiguousarray(va), n))
-        # the whole shard as one matrix (chunks == 1 callers, tests)
-        self.row_ptr, self.col_idx, self.val = self.pieces[0][:3] if self.chunks == 1 else (None, None, None)
+        # the rank's shard as ONE matrix
+        rp, ci, va = partition.take_rows(row_ptr, col_idx, val, self.r0, self.r1)
+        self.row_ptr, self.col_idx, self.val = np.ascontiguousarray(rp), self.layout.to_slotted_index(ci), np.ascontiguousarray(va)
+        self._pieces = None
+
+    @property
+    def pieces(self):
+        """Per chunk: (row_ptr, col_idx in layout positions, val, rows) -- the CPU test double computes piece by piece."""
+        if self._pieces is None:
+            self._pieces = []
+            for c in range(self.chunks):
+                lo, n = self.layout.piece_rows(self.rank, c)
+                rp, ci, va = partition.take_rows(self.row_ptr, self.col_idx, self.val, lo, lo + n)
+                self._pieces.append((np.ascontiguousarray(rp), ci, va, n))
+        return self._pieces
 
 
 class HipLocalStep:
-    """Local step on the GPU through the C ABI (sh_spmv_step) on torch-owned buffers; one matrix per chunk."""
+    """Local step on the GPU through the C ABI (sh_spmv_step_pieces) on torch-owned buffers: one device matrix per
+    rank, one launch per iteration, pieces reported as they complete."""
+
+    MAX_PIECES = 8
 
     def __init__(self, plan, semiring, device_index):
+        import ctypes as C
+
         import torch
+
+        from . import abi
         from .engine import Engine
-        self.torch = torch
+        if plan.chunks > self.MAX_PIECES:
+            raise ValueError(f"at most {self.MAX_PIECES} chunks per rank")
+        self.torch, self.C, self.abi = torch, C, abi
         self.plan, self.semiring = plan, semiring
         self.engine = Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
-        self.mats = [self.engine.upload_csr(n, plan.layout.length, rp, ci, np.ascontiguousarray(va, _np_dtype(semiring)))
-                     for rp, ci, va, n in plan.pieces]
-        self.A = self.mats[0]
+        self.A = self.engine.upload_csr(plan.rows, plan.layout.length, plan.row_ptr, plan.col_idx,
+                                        np.ascontiguousarray(plan.val, _np_dtype(semiring)))
         self.device = torch.device("cuda", device_index)
         self._wrapped = {}   # data_ptr -> engine vector handles (the driver ping-pongs two buffers)
+        lay, k = plan.layout, plan.rank
+        self.pc = abi.sh_row_pieces()
+        self.pc.n_pieces, self.pc.piece_rows, self.pc.report = plan.chunks, max(lay.piece, 1), 1
+        for c in range(plan.chunks):
+            self.pc.element_of_piece[c] = lay.piece_offset(k, c)
+        self.round, self.words = 0, None
 
     def _vec(self, ptr, n):
         v = self._wrapped.get((ptr, n))
@@ -86,21 +108,36 @@ class HipLocalStep:
             v = self._wrapped[(ptr, n)] = self.engine.wrap(ptr, n)
         return v
 
-    def step(self, c, x_cur, y_piece, x_next, alpha, beta, delta):
-        """Chunk c of this rank: x_next[piece c] = kernel(A_c, x_cur, y_piece); raises the rank's changed word."""
-        lay, k = self.plan.layout, self.plan.rank
-        rows = self.plan.pieces[c][3]
+    def launch(self, x_cur, y_vec, x_next, alpha, beta, delta):
+        """All pieces of this rank in one launch: x_next[pieces] = kernel(A, x_cur, y_vec[pieces]); raises the rank's
+        changed word; y_vec is a vector in the layout of x (x_cur itself from the second iteration on)."""
+        C, lay, k = self.C, self.plan.layout, self.plan.rank
         flag = self._vec(x_next.data_ptr() + lay.flag_index(k) * 4, lay.FLAG_PAD)
-        if c == 0:
-            flag.fill(0, np.int32)   # clear my changed word (async, same stream)
-        if rows == 0:
+        flag.fill(0, np.int32)   # clear my changed word (async, same stream)
+        if self.plan.rows == 0:
+            self.round = None
             return
-        off = lay.piece_offset(k, c)
         x = self._vec(x_cur.data_ptr(), lay.length)
-        y = self._vec(y_piece.data_ptr(), rows)
-        out = self._vec(x_next.data_ptr() + off * 4, rows)
-        self.engine.step(self.semiring, self.mats[c], x, y, alpha, beta, out, x_row_offset=off, delta=delta,
-                         changed_ptr=flag.device_ptr)
+        y = self._vec(y_vec.data_ptr(), lay.length)
+        out = self._vec(x_next.data_ptr(), lay.length)
+        dt = _np_dtype(self.semiring)
+        a, b = np.array([alpha], dt), np.array([beta], dt)
+        rnd, words = C.c_uint32(), C.POINTER(C.c_uint32)()
+        self.engine._chk(self.abi.load().sh_spmv_step_pieces(
+            self.engine.h, self.semiring, self.A.h, x.h, y.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+            out.h, C.byref(self.pc), delta, C.c_void_p(flag.device_ptr), C.byref(rnd), C.byref(words)))
+        self.round = rnd.value
+        self.words = np.ctypeslib.as_array(words, (self.MAX_PIECES,))
+
+    def wait_piece(self, c, timeout_s=30.0):
+        """Host-side wait until piece c of the launch in flight is written and visible system-wide."""
+        if self.round is None:
+            return
+        import time
+        t0 = time.perf_counter()
+        while self.words[c] < self.round:   # (a word in host memory the reporting launch writes)
+            if time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError(f"piece {c} of round {self.round} was not reported within {timeout_s} s")
 
 
 class ShardedIteration:
@@ -124,7 +161,8 @@ class ShardedIteration:
         fill = x0.dtype.type(0)
         x_cur = torch.from_numpy(lay.scatter(x0, fill)).to(dev)
         x_next = torch.zeros_like(x_cur)
-        y_first = torch.from_numpy(np.ascontiguousarray(y0[plan.r0:plan.r1])).to(dev)
+        y_lay = torch.from_numpy(lay.scatter(y0, fill)).to(dev)   # y of the first iteration, in the layout of x
+        side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         flag_i = lay.flag_index(k)
         flag_idx = torch.tensor([lay.flag_index(j) for j in range(world)], device=dev, dtype=torch.long)
         flags_dev = torch.zeros(world, dtype=torch.int32, device=dev)
@@ -134,6 +172,8 @@ class ShardedIteration:
             flags_host = flags_host.pin_memory()
             copied = torch.cuda.Event()
         clears_own_flag = isinstance(self.local, HipLocalStep)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
         iters, converged = 0, False
         if dev.type == "cuda":
             torch.cuda.synchronize()
@@ -142,21 +182,36 @@ class ShardedIteration:
             if not clears_own_flag:
                 x_next[flag_i:flag_i + lay.FLAG_PAD] = 0
             pending = []
+            y_vec = y_lay if iters == 0 else x_cur
+            self.local.launch(x_cur, y_vec, x_next, alpha, beta, delta)
             for c in range(chunks):
-                lo, n = lay.piece_rows(k, c)
-                off = lay.piece_offset(k, c)
-                y_piece = y_first[lo:lo + max(n, 1)] if iters == 0 else x_cur[off:off + max(n, 1)]
-                self.local.step(c, x_cur, y_piece, x_next, alpha, beta, delta)
+                self.local.wait_piece(c)
                 if world > 1:
                     start, length = lay.region(c)
                     region = x_next[start:start + length]
                     mine = region[k * lay.piece_len(c):(k + 1) * lay.piece_len(c)]
                     if dev.type == "cpu":
                         mine = mine.clone()   # gloo does not take an input aliasing the output
-                    # asynchronous: ordered behind the step just enqueued, concurrent with the next chunk's step
-                    pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
+                        pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
+                    elif dist.get_backend() == "gloo":
+                        # rehearsal on one GPU (ranks share the card, gloo has no device all-gather): through the host.
+                        # The piece is complete and visible: the side stream copies it out while the launch goes on.
+                        with torch.cuda.stream(side):
+                            mine_h = mine.to("cpu", non_blocking=True)
+                            side.synchronize()
+                            region_h = torch.empty(length, dtype=region.dtype)
+                            dist.all_gather_into_tensor(region_h, mine_h)
+                            region.copy_(region_h, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            pending.append(ev)
+                    else:
+                        # piece c is complete and visible (the host has seen its report): its exchange need not wait for
+                        # the launch, which is still computing the later pieces on the main stream
+                        with torch.cuda.stream(side):
+                            pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
             for w in pending:
-                w.wait()
+                w.wait()   # (the main stream waits: collective work or the event behind a staged copy)
             torch.index_select(x_next.view(torch.int32), 0, flag_idx, out=flags_dev)
             flags_host.copy_(flags_dev, non_blocking=True)
             if copied is not None:

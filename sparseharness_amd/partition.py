@@ -20,18 +20,23 @@ import numpy as np
 def row_bounds(row_ptr, parts, cols=None):
     """Boundaries b[0..parts] of contiguous row ranges of ~equal WORK.
 
-    Without `cols`: equal stored entries per range.  With `cols` (the x length) and a matrix big
-    enough for the engine's x-tiled plan, entries are weighted by the HBM bytes that plan moves
-    for them: ~18 B for an entry of a light row, ~7 B for an entry of a heavy row (rows averaging
-    >= 8 entries per 32768-column tile, pre-reduced inside phase 1).  A shard
-    full of heavy rows would otherwise finish early while the others still stream."""
-    row_ptr = np.asarray(row_ptr)
+    Without `cols`: equal stored entries per range.  With `cols` (the x length) the rows are weighted by the HBM
+    bytes the engine expects to move for them under the plan it would choose (sh_plan_row_work of the C ABI: an
+    entry of a heavy row -- pre-reduced inside phase 1 of the x-tiled plan -- costs a third of an entry of a light
+    row), so that the engine's layout rules and the sharding cannot drift apart.  A shard full of
+    heavy rows would otherwise finish early while the others still stream."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
     rows = len(row_ptr) - 1
-    if cols is not None and cols > (1 << 20) and int(row_ptr[-1]) >= (1 << 22):
-        deg = np.diff(row_ptr).astype(np.int64)
-        thr = max(512, 8 * ((int(cols) + 32767) // 32768))
-        work = np.where(deg >= thr, 7 * deg, 18 * deg)
-        cum = np.concatenate([[0], np.cumsum(work)])
+    if cols is not None:
+        import ctypes as C
+
+        from . import abi
+        cum = np.zeros(rows + 1, np.uint64)
+        rc = abi.load().sh_plan_row_work(rows, int(cols), int(row_ptr[-1]), row_ptr.ctypes.data_as(C.c_void_p), None,
+                                         cum.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(f"sh_plan_row_work failed: {rc}")
+        cum = cum.astype(np.int64)
     else:
         cum = row_ptr.astype(np.int64)
     total = int(cum[-1])

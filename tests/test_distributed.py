@@ -27,6 +27,17 @@ class OracleLocalStep:
     def __init__(self, plan, semiring):
         self.plan, self.semiring = plan, semiring
 
+    def launch(self, x_cur, y_vec, x_next, alpha, beta, delta):
+        """All pieces of the rank (the HIP step is one launch that reports its pieces one by one; this double computes
+        them one by one up front)."""
+        for c in range(self.plan.chunks):
+            off = self.plan.layout.piece_offset(self.plan.rank, c)
+            rows = self.plan.pieces[c][3]
+            self.step(c, x_cur, y_vec[off:off + max(rows, 1)], x_next, alpha, beta, delta)
+
+    def wait_piece(self, c):
+        pass
+
     def step(self, c, x_cur, y_piece, x_next, alpha, beta, delta):
         p, lay = self.plan, self.plan.layout
         rp, ci, va, rows = p.pieces[c]
@@ -44,7 +55,7 @@ class OracleLocalStep:
             changed = bool((~(np.abs(prev - out).astype(np.float64) < delta)).any())
         xn = x_next.numpy().view(dt)
         xn[off:off + rows] = out
-        if changed:   # (the driver cleared the word before chunk 0; every chunk may raise it)
+        if changed:   # (the driver cleared the word before the launch; every piece may raise it)
             x_next.numpy().view(np.int32)[lay.flag_index(p.rank)] = 1
 
 

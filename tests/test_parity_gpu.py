@@ -482,9 +482,9 @@ def test_full_size_powerlaw_properties(eng, rows, nnz, plan):
 @pytest.mark.parametrize("chunks", [1, 3])
 @pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
 def test_sharded_driver_with_hip_local_step(cases, sr, chunks):
-    """The multi-GPU iteration driver's device seam (HipLocalStep -> sh_spmv_step on torch memory,
-    slotted / chunked vector layout, one matrix per chunk, fused changed flag raised by any chunk) on one
-    rank; the N>1 logic is covered under gloo."""
+    """The multi-GPU iteration driver's device seam (HipLocalStep -> sh_spmv_step_pieces on torch memory,
+    slotted / chunked vector layout, ONE matrix per rank whose launch reports its pieces one by one, fused
+    changed flag) on one rank; two ranks: test_two_ranks_share_the_gpu_with_hip_local_step."""
     import torch
     from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
     rp, ci, va, n = cases["rmat15"]
@@ -745,3 +745,61 @@ def test_many_launches_with_changing_inputs_midsize(eng, plan):
         xv.free()
     out.free()
     A.free()
+
+
+def _two_rank_worker(rank, world, port, sr, chunks, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
+        rp, ci, va = H.rmat(15, seed=5)
+        n = len(rp) - 1
+        vals = va.astype(O.elem_dtype(sr))
+        a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+        x0 = O.initial_vector(sr, n)
+        torch.cuda.set_device(0)
+        plan = ShardPlan(rp, ci, vals, rank, world, chunks)
+        final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0)).run(x0, x0, a, b, 1e-4, 60)
+        q.put((rank, final, iters, conv, plan.r0, plan.r1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+@pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32])
+def test_two_ranks_share_the_gpu_with_hip_local_step(sr, chunks, plan):
+    """N > 1 x HIP: two ranks, both on GPU 0 (the box has one), each with its own engine, its own half of an R-MAT-15
+    graph with columns remapped to the slotted layout, rank 1 writing its pieces at non-zero offsets, the two
+    changed flags travelling with the last piece; the all-gather goes through gloo (host-staged).  SSSP and BFS to
+    convergence, every rank's final vector and launch count bit-identical to the single-process oracle loop."""
+    if plan != "tiled":
+        pytest.skip("once per run is enough (the engine picks the plan by size)")
+    import socket
+
+    import torch.multiprocessing as mp
+    rp, ci, va = H.rmat(15, seed=5)
+    n = len(rp) - 1
+    vals = va.astype(O.elem_dtype(sr))
+    a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+    x0 = O.initial_vector(sr, n)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 60)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, sr, chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][4] > 0 and res[0][5] == res[1][4]          # rank 1 starts where rank 0 ends, past row 0
+    for rank, final, iters, conv, _, _ in res:
+        assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
+        np.testing.assert_array_equal(bits(final), bits(want))

@@ -771,7 +771,9 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int t = 0; t < CT; t++) n += (run_len[(size_t)t] + c - 1) / c + (hrel[(size_t)t] + c - 1) / c;
     return n;
   };
-  int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(65536) >= 6ll * std::max(n_cus, 1) ? 65536 : 49152);
+  // Round 3 (pair folding, same box): 48 K 0.453, 64 K 0.443, 96 K 0.448, 128 K 0.437 ms at full size -> 128 K under the same rule.
+  const int64_t enough = 6ll * std::max(n_cus, 1);
+  int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(131072) >= enough ? 131072 : (items_at(65536) >= enough ? 65536 : 49152));
   chunk = std::max<int64_t>(1024, chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips
   const bool xcd_order = opt.xcd_order != 0;
   // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).

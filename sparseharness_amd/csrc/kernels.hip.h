@@ -105,21 +105,23 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
   const int64_t at = row_element(st, row);
   T yv = use_y ? from_bits<T>(y[at]) : SR::identity();
   T o = SR::epilogue(dot, alpha, yv, beta, use_y);
-  out[at] = to_bits<T>(o);
+  // A launch that reports its pieces (StepDev::done) writes its rows THROUGH to memory: once the storing wave has
+  // drained (s_waitcnt vmcnt(0)) they are visible system-wide and a report needs no write-back of the XCD's L2.
+  // (Measured, R-MAT-23 SSSP / BFS iteration on one GPU, profiles/r03_piece_reporting_cost.log: plain stores + one
+  // asynchronous buffer_wbl2 per report and workgroup +5 % at 4 pieces, +11 % at 8; write-through rows +2 % / +0 %.)
+  if (st.done) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else out[at] = to_bits<T>(o);
   if (st.changed) {
     T in = from_bits<T>(st.prev[st.prev_off + at]);
     if (SR::differs(in, o, st.delta))
-      *st.changed = 1;   // benign race: every writer stores 1
+      *st.changed = 1;   // benign race: every writer stores 1 (a reporting launch publishes the word with its last piece)
   }
 }
 
-// One workgroup reports "my rows of pieces [c0, c1) are written".  Called by ONE lane after every wave of the
-// workgroup has drained its stores (s_waitcnt vmcnt(0)) and met at a barrier: a release at system scope (the rows
-// are read next by a collective / a copy engine / a peer), then one arrival per piece; the arrival that completes
-// a launch's round tells the host, which polls done_host[c].
-__device__ inline void pieces_done(const StepDev &st, int c0, int c1) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md)
+// One workgroup reports "my rows of pieces [c0, c1) are written".  Called by ONE lane after every storing wave of
+// the workgroup has drained its (write-through) row stores and the workgroup has met at a barrier: one arrival per
+// piece; the arrival that completes a launch's round tells the host, which polls done_host[c].
+__device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
   for (int c = c0; c < c1; c++) {
     const uint32_t n = __hip_atomic_fetch_add(st.done + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (n % st.expected == 0u)
@@ -130,14 +132,12 @@ __device__ inline void pieces_done(const StepDev &st, int c0, int c1) {
 // After launches that do not report by themselves (CSR-stream plan, a matrix of heavy rows only): one more tiny
 // launch on the same stream -- every row is written by then -- completes the round of every piece.
 __global__ void report_all_pieces(StepDev st) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (launched behind the kernels that wrote the rows: a kernel boundary, their write-through stores are complete)
+  if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int c = 0; c < st.n_pieces; c++) {
       const uint32_t n = __hip_atomic_fetch_add(st.done + c, st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + st.expected;
       __hip_atomic_store(st.done_host + c, n / st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-  }
 }
 
 
@@ -877,7 +877,8 @@ __device__ __forceinline__ void tiled_phase2_run(
   auto bin_at = [&](int j) -> RowBin { return bins[b0 + min(j, nb - 1) * stride]; };   // clamped: scalar loads
   // Piece reporting (StepDev::done): once this workgroup has reduced j of its bins, every piece whose bins all lie
   // below its next bin is complete as far as this workgroup is concerned (its heavy rows were written before the
-  // first bin).  Wave-uniform and identical in both roles: all waves drain their stores and meet, one lane reports.
+  // first bin).  Wave-uniform and identical in both roles: the reducers drain their row stores, all waves meet, one
+  // lane arrives.  (The loaders store nothing: their prefetch window stays in flight.)
   int reported = 0;   // pieces [0, reported) reported
   auto report = [&](int j_done) {
     if (st.done == nullptr || reported >= st.n_pieces) return;
@@ -885,9 +886,18 @@ __device__ __forceinline__ void tiled_phase2_run(
     int upto = reported;
     while (upto < st.n_pieces && st.piece_bin_end[upto] <= next_bin) upto++;
     if (upto == reported) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == P2S_LD) pieces_done(st, reported, upto);
+    if (tid >= P2S_LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == P2S_LD) {
+      // the changed word travels with the last piece: it was raised by plain stores (millions of rows may raise it: they
+      // stay in the XCD's L2); this workgroup's share of it is written through once, ahead of its last arrival
+      if (upto == st.n_pieces && st.changed != nullptr &&
+          __hip_atomic_load(st.changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(st.changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      pieces_arrive(st, reported, upto);
+    }
     reported = upto;
   };
   if (tid < 8)

@@ -122,6 +122,9 @@ typedef struct sh_plan_options {
   int32_t xcd_order;       /* 1: phase-1 work items ordered so that an XCD stages only its eighth of x        [SH_XCD_ORDER] */
   int32_t fold;            /* 1: phase 1 folds the entries of one row inside one column tile into ONE product before
                               it travels through P (a fifth of the light products of a power-law matrix)       [SH_FOLD]     */
+  int32_t or_and_bits;     /* 1: also build the bit-blocked layout that SH_OR_AND_I32 launches then run on (x as a bitmap,
+                              4 B per entry, no product array: a BFS iteration moves a third of the bytes); 2: ONLY
+                              that layout (the matrix then serves SH_OR_AND_I32 alone)                          [SH_OR_AND_BITS] */
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
@@ -140,7 +143,8 @@ int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
 int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes);
 /* Which execution plan sh_csr_upload chose (SH_PLAN=stream|tiled|auto overrides):
  * 0 = CSR-stream (x gathered from global memory, for L2-resident x),
- * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM).
+ * 1 = x-tiled two-phase (x tiles staged in LDS, products re-binned through HBM),
+ * 2 = the bit-blocked (or,and) layout alone (sh_plan_options::or_and_bits = 2).
  * streamed_bytes = HBM bytes one SpMV moves by construction under that plan (tiled: 2.5, 3 or 6 B per
  * stream entry + 4 B written and ~6.2 B re-read per product that travels through P + the vectors; the
  * measured figure of a layout is in profiles/measured_traffic.json). */

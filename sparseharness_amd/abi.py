@@ -25,7 +25,7 @@ class sh_launch(C.Structure):
 class sh_plan_options(C.Structure):
     """Plan options of sh_csr_upload_ex (field comments: include/sparseharness_hip.h)."""
     _fields_ = [("plan", C.c_int32), ("autotune", C.c_int32), ("value_coding", C.c_int32), ("build_threads", C.c_int32),
-                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32)]
+                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32), ("or_and_bits", C.c_int32)]
 
 
 class sh_row_pieces(C.Structure):

@@ -7,6 +7,7 @@
 // No CPU fallback: every compute entry point needs a live HIP device.
 #include "../../include/sparseharness_hip.h"
 #include "kernels.hip.h"
+#include "bits.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -73,6 +74,15 @@ struct sh_csr {
   int fold = 0;                               // phase 1 folds a row's entries inside a tile into one product
   size_t stream_bytes = 0, tiled_bytes = 0;   // device memory held by the arrays of plan A / plan B
   std::vector<int32_t> bin_r0;                // first row of every row bin (host copy: piece reporting)
+  // the (or,and) semiring on bits (bits.hip.h); built when sh_plan_options::or_and_bits asks for it
+  BitsItem *d_bits_items = nullptr;
+  uint32_t *d_bits_ent = nullptr, *d_bits_partial = nullptr;
+  int32_t *d_bits_sub = nullptr, *d_bits_rr0 = nullptr;
+  uint64_t *d_xbits = nullptr;
+  int32_t n_bits_items = 0, bits_ct = 0;
+  int64_t bits_entries = 0;
+  size_t bits_bytes = 0;
+  bool bits_only = false;                     // no other plan was built: only SH_OR_AND_I32 launches are served
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
   uint32_t round = 0;                         // reporting launches so far
 };
@@ -851,6 +861,75 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   return true;
 }
 
+// ---- the (or,and) semiring on bits (see bits.hip.h) -----------------------
+struct BitsHost {
+  std::vector<BitsItem> items;
+  std::vector<uint32_t> ent;
+  std::vector<int32_t> bsub, rr_item0;
+  int32_t n_rr = 0, n_ct = 0;
+  int64_t entries = 0;   // entries with a non-zero value and a column in range
+};
+// Entries of row range rr / column block ct, ordered by row (the CSR walk is row-major), every 8192-row sub-range
+// padded to a multiple of 8 entries with copies of its last entry; blocks with more than `max_item` entries are cut
+// at sub-range boundaries into several work items.
+static bool build_bits_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp, const int32_t *ci, const uint32_t *val,
+                            const sh_plan_options &opt, BitsHost &H) {
+  H.n_rr = (int32_t)std::max<int64_t>(1, (rows + BITS_BR - 1) / BITS_BR);
+  H.n_ct = (int32_t)std::max<int64_t>(1, (cols + BITS_BC - 1) / BITS_BC);
+  const int NT = build_threads(opt);
+  const int64_t nblk = (int64_t)H.n_rr * H.n_ct, ncell = nblk * BITS_NSUB;
+  if (ncell > (int64_t)1 << 27) return false;   // (a 500 M x 500 M matrix: shard it)
+  std::vector<int64_t> cnt((size_t)ncell + 1, 0), start((size_t)ncell + 1, 0);
+  auto cell_of = [&](int64_t r, int32_t c) { return (((r / BITS_BR) * H.n_ct + c / BITS_BC) * BITS_NSUB) + (r % BITS_BR) / BITS_SUB; };
+  auto live = [&](int32_t j) { return val[j] != 0u && (uint32_t)ci[j] < (uint32_t)cols; };   // bool_and(x, a): a != 0; out of range: identity 0
+  parallel_items(H.n_rr, 1, NT, [&](int64_t rr, int) {   // a row range owns its cells
+    for (int64_t r = rr * BITS_BR; r < std::min<int64_t>(rows, (rr + 1) * BITS_BR); r++)
+      for (int32_t j = rp[r]; j < rp[r + 1]; j++)
+        if (live(j)) cnt[(size_t)cell_of(r, ci[j])]++;
+  });
+  int64_t pos = 0;
+  for (int64_t k = 0; k < ncell; k++) { start[(size_t)k] = pos; pos += (cnt[(size_t)k] + 7) & ~int64_t(7); H.entries += cnt[(size_t)k]; }
+  start[(size_t)ncell] = pos;
+  if (pos > INT32_MAX - 8) return false;
+  H.ent.assign((size_t)pos + 8, 0u);
+  parallel_items(H.n_rr, 1, NT, [&](int64_t rr, int) {
+    std::vector<int64_t> cur((size_t)H.n_ct * BITS_NSUB);
+    for (int64_t k = 0; k < (int64_t)cur.size(); k++) cur[(size_t)k] = start[(size_t)(rr * H.n_ct * BITS_NSUB + k)];
+    for (int64_t r = rr * BITS_BR; r < std::min<int64_t>(rows, (rr + 1) * BITS_BR); r++)
+      for (int32_t j = rp[r]; j < rp[r + 1]; j++)
+        if (live(j)) {
+          const int64_t cell = cell_of(r, ci[j]) - rr * H.n_ct * BITS_NSUB;
+          H.ent[(size_t)cur[(size_t)cell]++] = (uint32_t)(ci[j] % BITS_BC) | ((uint32_t)(r % BITS_SUB) << 19);
+        }
+    for (int64_t k = 0; k < (int64_t)cur.size(); k++) {   // pad with copies of the last entry
+      const int64_t cell = rr * H.n_ct * BITS_NSUB + k, end = start[(size_t)cell] + ((cnt[(size_t)cell] + 7) & ~int64_t(7));
+      for (int64_t q = cur[(size_t)k]; q < end; q++) H.ent[(size_t)q] = H.ent[(size_t)cur[(size_t)k] - 1];
+    }
+  });
+  const int64_t max_item = 1 << 20;
+  H.rr_item0.assign((size_t)H.n_rr + 1, 0);
+  for (int32_t rr = 0; rr < H.n_rr; rr++) {
+    H.rr_item0[(size_t)rr] = (int32_t)H.items.size();
+    for (int32_t ct = 0; ct < H.n_ct; ct++) {
+      const int64_t c0 = ((int64_t)rr * H.n_ct + ct) * BITS_NSUB;
+      if (start[(size_t)(c0 + BITS_NSUB)] == start[(size_t)c0]) continue;   // an empty block
+      for (int sub0 = 0; sub0 < BITS_NSUB;) {
+        int sub1 = sub0 + 1;
+        while (sub1 < BITS_NSUB && start[(size_t)(c0 + sub1 + 1)] - start[(size_t)(c0 + sub0)] <= max_item) sub1++;
+        if (start[(size_t)(c0 + sub1)] > start[(size_t)(c0 + sub0)]) {
+          BitsItem it{rr, ct, (int32_t)start[(size_t)(c0 + sub0)], (int32_t)start[(size_t)(c0 + sub1)], sub0, sub1, (int32_t)H.bsub.size(), 0};
+          for (int k = sub0; k <= sub1; k++) H.bsub.push_back((int32_t)start[(size_t)(c0 + k)]);
+          H.items.push_back(it);
+        }
+        sub0 = sub1;
+      }
+    }
+  }
+  H.rr_item0[(size_t)H.n_rr] = (int32_t)H.items.size();
+  (void)nnz;
+  return true;
+}
+
 static int dispatch(sh_engine *e, sh_semiring sr, const sh_csr *A, const sh_vec *x, const sh_vec *y,
                     const void *alpha, const void *beta, sh_vec *out, StepDev st);
 
@@ -946,6 +1025,7 @@ void sh_plan_options_default(sh_plan_options *o) {
   o->chunk = 0;   // auto (see build_tiled_plan)
   o->xcd_order = 1;
   o->fold = 1;
+  o->or_and_bits = 0;
 }
 
 void sh_plan_options_from_env(sh_plan_options *o) {
@@ -960,6 +1040,7 @@ void sh_plan_options_from_env(sh_plan_options *o) {
   num("SH_CHUNK", o->chunk);
   if (const char *v = getenv("SH_XCD_ORDER")) o->xcd_order = v[0] != '0';
   if (const char *v = getenv("SH_FOLD")) o->fold = v[0] != '0';
+  num("SH_OR_AND_BITS", o->or_and_bits);
 }
 
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
@@ -1009,6 +1090,31 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       HIP_TRY_M(hipMemcpyAsync((ptr), (host), (size_t)(bytes), hipMemcpyHostToDevice, e->stream));            \
   } while (0)
 
+  // The (or,and) semiring on bits, when asked for (or_and_bits: 1 = beside the ordinary plan, 2 = instead of it: a BFS
+  // harness never launches another semiring on its matrix)
+  size_t *acct = &m->bits_bytes;
+  if (opt.or_and_bits > 0 && nnz > 0) {
+    BitsHost bh;
+    if (build_bits_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, bh)) {
+      m->n_bits_items = (int32_t)bh.items.size();
+      m->bits_ct = bh.n_ct;
+      m->bits_entries = bh.entries;
+      m->bits_only = opt.or_and_bits >= 2;
+      DEV_ARRAY(m->d_bits_items, bh.items.data(), bh.items.size() * sizeof(BitsItem), 32);
+      DEV_ARRAY(m->d_bits_ent, bh.ent.data(), bh.ent.size() * 4, 16);
+      DEV_ARRAY(m->d_bits_sub, bh.bsub.data(), bh.bsub.size() * 4, 16);
+      DEV_ARRAY(m->d_bits_rr0, bh.rr_item0.data(), bh.rr_item0.size() * 4, 0);
+      DEV_ARRAY(m->d_xbits, (const uint64_t *)nullptr, (size_t)bh.n_ct * (BITS_BC / 8), 0);
+      DEV_ARRAY(m->d_bits_partial, (const uint32_t *)nullptr, (size_t)std::max<size_t>(bh.items.size(), 1) * (BITS_BR / 8), 0);
+      HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
+    }
+  }
+  if (m->bits_only && m->d_bits_items) {
+    m->plan = PLAN_STREAM;
+    *out = m;
+    return SH_OK;
+  }
+  m->bits_only = false;
   // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
   // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
   TiledHost th;
@@ -1018,7 +1124,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
   const bool tune = tiled && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5;
   m->plan = tiled ? PLAN_TILED : PLAN_STREAM;
-  size_t *acct = &m->stream_bytes;
+  acct = &m->stream_bytes;
   if (!tiled || tune) {
     std::vector<int32_t> pairs;
     std::vector<LongSeg> segs;
@@ -1108,7 +1214,8 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
                   (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
-                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase, (void *)m->d_done})
+                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase, (void *)m->d_done, (void *)m->d_bits_items,
+                  (void *)m->d_bits_ent, (void *)m->d_bits_partial, (void *)m->d_bits_sub, (void *)m->d_bits_rr0, (void *)m->d_xbits})
     if (p) (void)hipFree(p);
   if (m->h_done) (void)hipHostFree(m->h_done);
   delete m;
@@ -1135,7 +1242,12 @@ int sh_csr_algorithmic_bytes(const sh_csr *m, int reads_y, uint64_t *bytes) {
 int sh_csr_plan(const sh_csr *m, int32_t *plan, uint64_t *streamed_bytes) {
   if (!m)
     return SH_EINVAL;
-  if (plan) *plan = m->plan;
+  if (plan) *plan = m->bits_only ? 2 : m->plan;
+  if (streamed_bytes && m->bits_only) {   // 4 B per entry, the x bitmap and the partial result bitmaps written and read once, the vectors
+    *streamed_bytes = 4ull * (uint64_t)m->bits_entries + 2ull * (uint64_t)m->n_bits_items * (BITS_BR / 8) +
+                      (uint64_t)m->n_bits_items * (BITS_BC / 8) + 4ull * m->cols + 8ull * m->rows;
+    return SH_OK;
+  }
   if (streamed_bytes) {
     const uint64_t vec = 4ull * (m->rows + 1) + 4ull * m->cols + 4ull * m->rows;
     *streamed_bytes = (m->plan == PLAN_TILED)
@@ -1158,6 +1270,8 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
     snprintf(buf, buflen, "tiled values=%s tiles=%lld chunks=%d bins=%d heavy_rows=%d stream=%.1fM light=%.1fM products=%.1fM%s", vals,
              (long long)((m->cols + TCOLS - 1) / TCOLS), m->n_chunks, m->n_bins, m->n_tlong, m->stream_len / 1e6,
              m->light_entries / 1e6, m->p_len / 1e6, m->fold ? " folded" : "");
+  } else if (m->bits_only) {
+    snprintf(buf, buflen, "bits-only");
   } else {
     snprintf(buf, buflen, "stream values=raw blocks=%d long_rows=%d segments=%d", m->n_stream, m->n_long, m->n_segs);
   }
@@ -1167,7 +1281,10 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
   }
   {
     const size_t len = strlen(buf);
-    snprintf(buf + len, buflen - len, " device=%.3fGB", (double)(m->stream_bytes + m->tiled_bytes) / 1e9);
+    if (m->d_bits_items)
+      snprintf(buf + len, buflen - len, " or_and=bits(items=%d,entries=%.1fM%s)", m->n_bits_items, m->bits_entries / 1e6, m->bits_only ? ",only" : "");
+    const size_t len2 = strlen(buf);
+    snprintf(buf + len2, buflen - len2, " device=%.3fGB", (double)(m->stream_bytes + m->tiled_bytes + m->bits_bytes) / 1e9);
   }
   return SH_OK;
 }
@@ -1175,7 +1292,7 @@ int sh_csr_describe(const sh_csr *m, char *buf, size_t buflen) {
 int sh_csr_footprint(const sh_csr *m, uint64_t *device_bytes) {
   if (!m || !device_bytes)
     return SH_EINVAL;
-  *device_bytes = (uint64_t)(m->stream_bytes + m->tiled_bytes);
+  *device_bytes = (uint64_t)(m->stream_bytes + m->tiled_bytes + m->bits_bytes);
   return SH_OK;
 }
 
@@ -1282,6 +1399,32 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     return fail(e, SH_EINVAL, "sh_spmv: y is NULL but the epilogue reads it (beta != 0 or min-plus)");
   if (use_y && y->n < A->rows)
     return fail(e, SH_ESHAPE, "sh_spmv: y has %lld elements, matrix has %lld rows", (long long)y->n, (long long)A->rows);
+  if constexpr (std::is_same<SR, OrAndI32>::value) {
+    if (A->d_bits_items) {   // the (or,and) semiring on bits: x -> bitmap, blocks -> partial result bitmaps, rows
+      const int64_t words32 = (int64_t)A->bits_ct * (BITS_BC / 32);
+      hipLaunchKernelGGL(bits_pack_x, dim3((unsigned)((words32 * 8 + 255) / 256)), dim3(256), 0, e->stream, (const uint32_t *)x->d,
+                         (int32_t)A->cols, (uint32_t *)A->d_xbits, words32, st.gate);
+      HIP_TRY(e, hipGetLastError());
+      if (A->n_bits_items > 0) {
+        hipLaunchKernelGGL(bits_blocks, dim3((unsigned)A->n_bits_items), dim3(BITS_TBS), 0, e->stream, A->d_bits_items,
+                           A->d_bits_ent, A->d_bits_sub, (const uint32_t *)A->d_xbits, A->d_bits_partial, st.gate);
+        HIP_TRY(e, hipGetLastError());
+      }
+      if (A->rows > 0) {
+        hipLaunchKernelGGL(bits_finish, dim3((unsigned)((A->rows + BITS_FIN_ROWS - 1) / BITS_FIN_ROWS)), dim3(256), 0, e->stream, A->d_bits_rr0,
+                           A->d_bits_partial, (int32_t)A->rows, use_y ? (const uint32_t *)y->d : nullptr, alpha, beta, use_y ? 1 : 0,
+                           (uint32_t *)out->d, st);
+        HIP_TRY(e, hipGetLastError());
+      }
+      if (st.done) {
+        hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
+        HIP_TRY(e, hipGetLastError());
+      }
+      return SH_OK;
+    }
+  }
+  if (A->bits_only)
+    return fail(e, SH_EINVAL, "this matrix was uploaded with or_and_bits = 2: it serves SH_OR_AND_I32 launches only");
   if (A->plan == PLAN_TILED) {
     const uint32_t *yp = use_y ? (const uint32_t *)y->d : nullptr;
 #ifdef SH_STATS
@@ -1475,7 +1618,7 @@ int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x
     st.done = A->d_done;
     st.done_host = A->h_done;
     // arrivals per piece and launch: one per workgroup of phase 2, or the single one of report_all_pieces
-    st.expected = (A->plan == PLAN_TILED && A->n_bins > 0) ? (uint32_t)std::min(A->n_bins, e->n_cus) : 1u;
+    st.expected = (A->plan == PLAN_TILED && A->n_bins > 0 && !(sr == SH_OR_AND_I32 && A->d_bits_items)) ? (uint32_t)std::min(A->n_bins, e->n_cus) : 1u;
     A->round++;
     if (round) *round = A->round;
     if (done_words) *done_words = A->h_done;
@@ -1691,6 +1834,45 @@ int emulate(const TiledHost &H, int64_t rows, int64_t cols, const uint32_t *x, u
   return 0;
 }
 } // namespace
+
+// The (or,and) bit plan walked on the host: y[r] = OR over the live entries of row r of (x[col] != 0), through the
+// entry stream, the sub-range offsets and the item lists exactly as bits_blocks / bits_finish index them.
+extern "C" int sh_debug_emulate_bits(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx,
+                                     const void *val, const void *x, int32_t *y, int64_t *stats) {
+  sh_plan_options opt;
+  sh_plan_options_default(&opt);
+  BitsHost H;
+  if (!build_bits_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, H)) return -1;
+  const uint32_t *xv = (const uint32_t *)x;
+  std::vector<uint32_t> xbits((size_t)H.n_ct * (BITS_BC / 32), 0u), partial((size_t)std::max<size_t>(H.items.size(), 1) * (BITS_BR / 32), 0u);
+  for (int64_t c = 0; c < cols; c++) if (xv[c] != 0u) xbits[(size_t)c >> 5] |= 1u << (c & 31);
+  for (size_t k = 0; k < H.items.size(); k++) {
+    const BitsItem &it = H.items[k];
+    if ((it.s & 7) || (it.e & 7)) return -30;
+    const uint32_t *xs = &xbits[(size_t)it.ct * (BITS_BC / 32)];
+    uint32_t *os = &partial[k * (BITS_BR / 32)];
+    for (int sub = it.sub0; sub < it.sub1; sub++) {
+      const int32_t s = H.bsub[(size_t)it.soff + (sub - it.sub0)], e = H.bsub[(size_t)it.soff + (sub - it.sub0) + 1];
+      if ((s & 7) || (e & 7) || s < it.s || e > it.e) return -31;
+      for (int32_t q = s; q < e; q++) {
+        const uint32_t w = H.ent[(size_t)q], c = w & BITS_COL_MASK;
+        if ((xs[c >> 5] >> (c & 31)) & 1u) {
+          const uint32_t r = (uint32_t)sub * BITS_SUB + (w >> 19);
+          os[r >> 5] |= 1u << (r & 31);
+        }
+      }
+    }
+  }
+  for (int64_t r = 0; r < rows; r++) {
+    const int rr = (int)(r / BITS_BR);
+    const uint32_t rl = (uint32_t)(r % BITS_BR);
+    uint32_t w = 0;
+    for (int it = H.rr_item0[(size_t)rr]; it < H.rr_item0[(size_t)rr + 1]; it++) w |= partial[(size_t)it * (BITS_BR / 32) + (rl >> 5)];
+    y[r] = (int32_t)((w >> (rl & 31)) & 1u);
+  }
+  if (stats) { stats[0] = (int64_t)H.ent.size(); stats[1] = H.entries; stats[2] = (int64_t)H.items.size(); stats[3] = H.n_rr; stats[4] = H.n_ct; }
+  return 0;
+}
 
 extern "C" int sh_debug_emulate_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx,
                                      const void *val, const sh_plan_options *opt_p, int semiring, const void *x, void *y, int64_t *stats) {

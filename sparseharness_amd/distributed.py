@@ -91,8 +91,11 @@ class HipLocalStep:
         self.torch, self.C, self.abi = torch, C, abi
         self.plan, self.semiring = plan, semiring
         self.engine = Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
+        # (a large (or,and) shard goes up in the bit-blocked layout only, as in the BFS harness; SH_OR_AND_BITS overrides)
+        import os
+        bits = {"or_and_bits": 2} if (semiring == OR_AND_I32 and "SH_OR_AND_BITS" not in os.environ and len(plan.col_idx) >= 1 << 22) else {}
         self.A = self.engine.upload_csr(plan.rows, plan.layout.length, plan.row_ptr, plan.col_idx,
-                                        np.ascontiguousarray(plan.val, _np_dtype(semiring)))
+                                        np.ascontiguousarray(plan.val, _np_dtype(semiring)), **bits)
         self.device = torch.device("cuda", device_index)
         self._wrapped = {}   # data_ptr -> engine vector handles (the driver ping-pongs two buffers)
         lay, k = plan.layout, plan.rank

@@ -77,10 +77,10 @@ class CsrMatrix:
         return b.value
 
     def plan(self):
-        """('stream'|'tiled', HBM bytes one SpMV streams by construction)."""
+        """('stream'|'tiled'|'bits', HBM bytes one SpMV streams by construction)."""
         p, b = C.c_int32(), C.c_uint64()
         self.engine._chk(abi.load().sh_csr_plan(self.h, C.byref(p), C.byref(b)))
-        return ("stream", "tiled")[p.value], b.value
+        return ("stream", "tiled", "bits")[p.value], b.value
 
     def describe(self):
         """One-line description of the device layout (plan, value coding, tile/bin counts)."""

@@ -13,6 +13,7 @@
 // (app/sssp.cpp:147-150).  The semiring is read from the user functions named
 // in the JSON's OpenCL source, where the reference keeps it.
 #pragma once
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -124,10 +125,17 @@ protected:
     start_timer(allocateBuffers, Harness);
     unsigned int arg_index = 0;
     const int64_t nnz = (int64_t)(_args.m_idxs.size() / sizeof(int32_t));
-    checkSHError(_engine, sh_csr_upload(_engine, _args.rows, _args.cols, nnz,
-                                        reinterpret_cast<const int32_t *>(_args.m_row_ptr.data()),
-                                        reinterpret_cast<const int32_t *>(_args.m_idxs.data()), _args.m_vals.data(),
-                                        &_mem_manager._matrix));
+    // The plan knobs come from the SH_* environment, once per upload.  A harness knows its semiring for the life of
+    // its matrix (the reference compiles ONE kernel per harness, inc/harness.h:57-73): a large (or,and) matrix -- the
+    // BFS app -- is uploaded in the bit-blocked layout only (x as a bitmap, 4 B per entry), unless SH_OR_AND_BITS says otherwise.
+    sh_plan_options opt;
+    sh_plan_options_from_env(&opt);
+    if (_semiring == SH_OR_AND_I32 && getenv("SH_OR_AND_BITS") == nullptr && nnz >= (int64_t)1 << 22)
+      opt.or_and_bits = 2;
+    checkSHError(_engine, sh_csr_upload_ex(_engine, _args.rows, _args.cols, nnz,
+                                           reinterpret_cast<const int32_t *>(_args.m_row_ptr.data()),
+                                           reinterpret_cast<const int32_t *>(_args.m_idxs.data()), _args.m_vals.data(),
+                                           &opt, &_mem_manager._matrix));
     arg_index += 2; // idx, val
     _mem_manager._x_vect = createAndUploadGlobalArg(_args.x_vect, true);
     setGlobalArg(arg_index++, &_mem_manager._x_vect);

@@ -211,3 +211,15 @@ def test_headline_sizes_through_the_harness_boundary(spec, workload, expect_corr
     assert d["parity"]["mismatches_rel_1e-5"] == 0
     # one timed launch at a time (events around each launch) against 20 back-to-back launches: allow 15 %
     assert abs(app_ms - bench_ms) <= 0.15 * bench_ms, (app_ms, bench_ms)
+
+
+@pytest.mark.parametrize("host_loop", ["0", "1"])
+def test_bfs_app_on_the_bit_blocked_layout(matrix_name, host_loop):
+    """bfs_harness with the matrix uploaded in the bit-blocked (or,and) layout only (what the harness does by itself for
+    large matrices; forced here on the reference's example matrices): same launches, same final vector."""
+    g = golden(matrix_name)
+    r = run_app("bfs_harness", matrix_name, "bfs.json", {"SH_HOST_LOOP": host_loop, "SH_OR_AND_BITS": "2"}, "-x", "2000")
+    assert r.returncode == 0, r.stderr[-800:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("SH_RESULT")][0]
+    assert f"iterations={int(g['bfs_meta'][0])} converged={int(g['bfs_meta'][1])}" in res
+    assert res.endswith(f"set={int((g['bfs_final'] != 0).sum())}")

@@ -803,3 +803,82 @@ def test_two_ranks_share_the_gpu_with_hip_local_step(sr, chunks, plan):
     for rank, final, iters, conv, _, _ in res:
         assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
         np.testing.assert_array_equal(bits(final), bits(want))
+
+
+@pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_or_and_on_bits_matches_oracle(eng, cases, name, mode, plan):
+    """sh_plan_options::or_and_bits: SH_OR_AND_I32 launches run on the bit-blocked layout (x as a bitmap, 4-byte
+    coordinate entries, partial result bitmaps; bits.hip.h) -- beside the ordinary plan (1) or instead of it (2).
+    Every epilogue form, entries with a zero value, and an iteration loop to convergence, bit-exact against the
+    oracle; with mode 1 the other semirings still run on the ordinary plan, with mode 2 they are refused."""
+    if plan != "tiled":
+        pytest.skip("once per run (the bit layout does not depend on the float plans)")
+    rp, ci, va, n = cases[name]
+    rng = np.random.default_rng(17)
+    vals = va.astype(np.int32)
+    vals[rng.integers(0, len(vals), len(vals) // 9)] = 0
+    A = eng.upload_csr(n, n, rp, ci, vals, or_and_bits=mode)
+    assert "or_and=bits(" in A.describe() and ("only" in A.describe()) == (mode == 2), A.describe()
+    out = eng.alloc(n).fill(0)
+    for density, a, b in [(0.0, 1, 0), (0.01, 1, 0), (0.3, 1, 1), (1.0, 0, 1), (0.05, 3, 0)]:
+        x = ((rng.random(n) < density) * rng.integers(1, 5, n)).astype(np.int32)
+        y = rng.integers(0, 2, n).astype(np.int32)
+        xv, yv = eng.vector(x), eng.vector(y)
+        eng.spmv(O.OR_AND_I32, A, xv, yv, a, b, out)
+        np.testing.assert_array_equal(out.download(np.int32), O.kernel(O.OR_AND_I32, rp, ci, vals, x, y, a, b))
+        xv.free()
+        yv.free()
+    x0 = O.initial_vector(O.OR_AND_I32, n)
+    want, w_it, w_conv = O.iterate(O.OR_AND_I32, rp, ci, vals, x0, x0, 1, 0, 1e-4, 100)
+    xv, yv, sc = eng.vector(x0), eng.vector(x0), eng.alloc(n)
+    iters, conv, _, _ = eng.iterate(O.OR_AND_I32, A, xv, yv, sc, 1, 0, 1e-4, 100)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(xv.download(np.int32), want)
+    fx = eng.vector(np.ones(n, np.float32))
+    if mode == 2:
+        with pytest.raises(Exception, match="SH_OR_AND_I32 launches only"):
+            eng.spmv(O.PLUS_TIMES_F32, A, fx, None, 1.0, 0.0, out)
+    else:
+        eng.spmv(O.MAX_MIN_I32, A, xv, yv, O.INT_MAX, O.INT_MIN, out)
+        np.testing.assert_array_equal(out.download(np.int32), O.kernel(O.MAX_MIN_I32, rp, ci, vals, xv.download(np.int32), x0, O.INT_MAX, O.INT_MIN))
+    for v in (xv, yv, sc, out, fx):
+        v.free()
+    A.free()
+
+
+def test_or_and_on_bits_wide_matrix_and_sharded_driver(monkeypatch, plan):
+    """More than one row range and column block (700 K x 1.3 M), then the multi-GPU iteration driver's device seam on
+    the bit layout (row -> element mapping of the pieces, piece reports) on one rank."""
+    if plan != "tiled":
+        pytest.skip("once per run")
+    import torch
+    from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
+    rng = np.random.default_rng(23)
+    rows, cols = 700_000, 1_300_000
+    deg = rng.poisson(4, rows).astype(np.int64)
+    deg[5] = 200_000
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, cols, int(rp[-1])).astype(np.int32)
+    vals = rng.integers(0, 3, int(rp[-1])).astype(np.int32)
+    x = (rng.random(cols) < 0.02).astype(np.int32)
+    y = rng.integers(0, 2, rows).astype(np.int32)
+    with Engine(0) as e2:
+        A = e2.upload_csr(rows, cols, rp, ci, vals, or_and_bits=2)
+        xv, yv, out = e2.vector(x), e2.vector(y), e2.alloc(rows).fill(0)
+        e2.spmv(O.OR_AND_I32, A, xv, yv, 1, 1, out)
+        np.testing.assert_array_equal(out.download(np.int32), O.kernel(O.OR_AND_I32, rp, ci, vals, x, y, 1, 1))
+    monkeypatch.setenv("SH_OR_AND_BITS", "1")
+    rp2, ci2, va2 = H.rmat(15, seed=5)
+    n = len(rp2) - 1
+    v2 = va2.astype(np.int32)
+    x0 = O.initial_vector(O.OR_AND_I32, n)
+    want, w_it, w_conv = O.iterate(O.OR_AND_I32, rp2, ci2, v2, x0, x0, 1, 0, 1e-4, 60)
+    torch.cuda.set_device(0)
+    sp = ShardPlan(rp2, ci2, v2, 0, 1, 3)
+    step = HipLocalStep(sp, O.OR_AND_I32, 0)
+    assert "or_and=bits(" in step.A.describe()
+    final, iters, conv = ShardedIteration(sp, O.OR_AND_I32, step).run(x0, x0, 1, 0, 1e-4, 60)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(bits(final), bits(want))

@@ -21,7 +21,7 @@ LIB = os.path.join(ROOT, "sparseharness_amd", "variants", "emulate.so")
 @pytest.fixture(scope="module")
 def emu():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "semiring.hip.h")]
+    src = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "bits.hip.h", "semiring.hip.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in src):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-Wno-unused-function", "-DSH_PLAN_EMULATE", src[0], "-o", LIB])
@@ -30,6 +30,8 @@ def emu():
     lib.sh_debug_emulate_plan.restype = C.c_int
     lib.sh_debug_emulate_plan.argtypes = [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.POINTER(abi.sh_plan_options), C.c_int,
                                                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sh_debug_emulate_bits.restype = C.c_int
+    lib.sh_debug_emulate_bits.argtypes = [C.c_int64] * 3 + [C.c_void_p] * 6
     return lib
 
 
@@ -124,3 +126,44 @@ def test_folding_removes_the_duplicates_of_a_row_inside_a_tile(emu):
     rc, y0, st0, _ = emulate(emu, rows, cols, rp, ci, va, 0, fold=0)
     assert rc == 0 and st0["products"] >= int(deg.sum())
     np.testing.assert_array_equal(y0, y)
+
+
+@pytest.mark.parametrize("shape", range(len(SHAPES)))
+def test_emulated_bit_plan_equals_boolean_product(emu, shape):
+    """The (or,and) semiring on bits (bits.hip.h): blocks of 262144 rows x 524288 columns, 4-byte coordinate entries in
+    8192-row sub-ranges padded to octets with copies, work items, partial bitmaps -- walked on the host and compared with the
+    boolean product, entries with a zero value or a column out of range included (they never contribute)."""
+    rows, cols, avg, heavy, kw = SHAPES[shape]
+    rng = np.random.default_rng(300 + shape)
+    rp, ci, va = random_matrix(rng, rows, cols, avg, heavy, **kw)
+    vals = va.astype(np.int32)
+    vals[rng.integers(0, max(len(vals), 1), len(vals) // 7)] = 0          # dead entries
+    for density in (0.0, 0.02, 0.5, 1.0):
+        x = (rng.random(cols) < density).astype(np.int32) * rng.integers(1, 9, cols).astype(np.int32)
+        y = np.full(rows, -1, np.int32)
+        st = np.zeros(8, np.int64)
+        rc = emu.sh_debug_emulate_bits(rows, cols, len(ci), _p(rp), _p(ci), _p(vals), _p(x), _p(y), _p(st))
+        assert rc == 0, rc
+        np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, vals, x, 2))
+        live = int(((vals != 0) & (ci >= 0) & (ci < cols)).sum())
+        assert st[1] == live and live <= st[0] <= live + 8 + 7 * 32 * st[3] * st[4]
+
+
+def test_bit_plan_on_a_matrix_spanning_several_blocks(emu):
+    """3 row ranges x 3 column blocks, a hub row, empty blocks (no work item for them)."""
+    rng = np.random.default_rng(11)
+    rows, cols = 600_000, 1_200_000
+    deg = rng.poisson(3, rows).astype(np.int64)
+    deg[123_456] = 300_000
+    deg[300_000:400_000] = 0
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, cols, int(rp[-1])).astype(np.int32)
+    ci[rp[500_000]:] = rng.integers(0, 400_000, int(rp[-1] - rp[500_000])).astype(np.int32)   # the last rows touch one column block only
+    vals = np.ones(int(rp[-1]), np.int32)
+    x = (rng.random(cols) < 0.01).astype(np.int32)
+    y = np.full(rows, -1, np.int32)
+    st = np.zeros(8, np.int64)
+    assert emu.sh_debug_emulate_bits(rows, cols, len(ci), _p(rp), _p(ci), _p(vals), _p(x), _p(y), _p(st)) == 0
+    np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, vals, x, 2))
+    assert st[3] == 3 and st[4] == 3 and st[2] <= 9

@@ -82,4 +82,17 @@ def test_tiled_kernels_use_no_scratch_and_spill_nothing():
     r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "sparseharness_amd", "csrc"), "asm-check"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
-    assert "0 offenders" in r.stdout
+    assert "0 offenders" in r.stdout and "0 reads of registers with a load in flight" in r.stdout
+    # and the prefetch check does bite: a copy of a prefetch register slipped in right behind its load is reported
+    import re
+    import sys
+    lines = open("/tmp/sh_engine_check.s").read().splitlines()
+    k = next(i for i, l in enumerate(lines) if l.startswith("_ZN2sh18spmv_tiled_phase2s"))
+    j = next(i for i in range(k, len(lines)) if lines[i].strip().startswith("global_load_dwordx4") and "#ASMSTART" in lines[i - 1])
+    dst = re.search(r"v\[(\d+):", lines[j]).group(1)
+    end = next(i for i in range(j, len(lines)) if "#ASMEND" in lines[i])
+    doctored = lines[:end + 1] + [f"\tv_mov_b32_e32 v1, v{dst}"] + lines[end + 1:]
+    open("/tmp/sh_engine_doctored.s", "w").write("\n".join(doctored))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "sparseharness_amd", "csrc", "check_prefetch.py"), "/tmp/sh_engine_doctored.s"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "touches in-flight" in r.stdout, r.stdout[-400:]

@@ -21,6 +21,7 @@
 #include <vector>
 #include <thread>
 #include <atomic>
+#include <chrono>
 
 using namespace sh;
 
@@ -355,6 +356,17 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   const bool fold = opt.fold != 0;
+#ifdef SH_PLAN_EMULATE
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!getenv("SH_BUILD_TIMES")) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+#else
+  auto lap = [](const char *) {};
+#endif
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
   const int64_t per_tile = std::max(1, opt.heavy_per_tile);
@@ -371,13 +383,44 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     std::vector<int64_t> pos;                       // per tile
     std::vector<int32_t> e_row, e_j, s_row, s_j;    // entries of a bin: unsorted / sorted by tile
     std::vector<int32_t> start;                     // per touched tile: first entry in s_*
-    std::vector<uint16_t> rt;                       // tiles of one row (products per row)
+    std::vector<int32_t> rcount, rtouched;          // row_tiles(): per-tile counts of one row
+    std::vector<int32_t> np, ns;                    // per tile: pairs / singles of the bin being sized
     std::vector<int32_t> row_next;                  // per row of the bin: next product index inside the row
     std::vector<int32_t> lp, ls;                    // pairs / singles of a piece (index of the first entry in s_*)
   };
   std::vector<Scratch> scratch((size_t)NT);
-  for (auto &sc : scratch) { sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); }
+  for (auto &sc : scratch) {
+    sc.count.assign((size_t)CT, 0); sc.pos.assign((size_t)CT, 0); sc.rcount.assign((size_t)CT, 0);
+    sc.np.assign((size_t)CT, 0); sc.ns.assign((size_t)CT, 0);
+  }
 
+  // fn(tile, entries of row r in that tile) for every tile the row touches (any order).  Short rows: a tiny insertion
+  // sort of the tile numbers; long rows: counting into the per-tile scratch (std::sort per row made the build 4x slower).
+  auto row_tiles = [&](Scratch &sc, int64_t r, auto fn) {
+    const int32_t d = rp[r + 1] - rp[r];
+    if (d <= 12) {
+      uint16_t t[12];
+      for (int32_t i = 0; i < d; i++) {
+        const uint16_t v = (uint16_t)tile_of(ci[rp[r] + i]);
+        int32_t k = i;
+        while (k > 0 && t[k - 1] > v) { t[k] = t[k - 1]; k--; }
+        t[k] = v;
+      }
+      for (int32_t i = 0; i < d;) {
+        int32_t k = i + 1;
+        while (k < d && t[k] == t[i]) k++;
+        fn((int)t[i], k - i);
+        i = k;
+      }
+    } else {
+      sc.rtouched.clear();
+      for (int32_t j = rp[r]; j < rp[r + 1]; j++) {
+        const int t = tile_of(ci[j]);
+        if (sc.rcount[(size_t)t]++ == 0) sc.rtouched.push_back(t);
+      }
+      for (int t : sc.rtouched) { fn(t, sc.rcount[(size_t)t]); sc.rcount[(size_t)t] = 0; }
+    }
+  };
   // 1. products per light row (= its length without folding; with folding sum over tiles of ceil(entries in the tile / 2)),
   //    light row offsets in products (heavy rows have light length 0 and carry bit 31) and row bins
   H.lrp.assign((size_t)rows + 1, 0u);
@@ -389,16 +432,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         if (is_heavy(r)) continue;
         const int32_t d = rp[r + 1] - rp[r];
         if (!fold || d <= 1) { nprod[(size_t)r] = d; continue; }
-        sc.rt.clear();
-        for (int32_t j = rp[r]; j < rp[r + 1]; j++) sc.rt.push_back((uint16_t)tile_of(ci[j]));
-        std::sort(sc.rt.begin(), sc.rt.end());
         int32_t n = 0;
-        for (size_t i = 0; i < sc.rt.size();) {
-          size_t k = i + 1;
-          while (k < sc.rt.size() && sc.rt[k] == sc.rt[i]) k++;
-          n += (int32_t)((k - i + 1) / 2);
-          i = k;
-        }
+        row_tiles(sc, r, [&](int, int32_t k) { n += (k + 1) / 2; });
         nprod[(size_t)r] = n;
       }
     });
@@ -412,6 +447,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     H.lrp[(size_t)rows] = acc;
     H.light_entries = le;
   }
+  lap("products per row + lrp");
   auto light_off = [&](int64_t r) { return (int64_t)(H.lrp[(size_t)r] & 0x7FFFFFFFu); };
   // Bins are filled up to TBIN products.  (Sizing them so that every CU gets the same number of
   // bins was tried for shard-sized matrices: the smaller (bin, tile) pieces cost more than the
@@ -484,23 +520,33 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       else { sc.ls.push_back(i); i += 1; }
     }
   };
-  // P1
+  // P1 (sizes only: pairs and singles per (bin, tile) from the rows' per-tile counts; the entries are not moved yet)
   parallel_items(n_bins, 8, NT, [&](int64_t bi, int th) {
     RowBin &b = H.bins[(size_t)bi];
     Scratch &sc = scratch[(size_t)th];
-    sort_bin(sc, b);
+    sc.touched.clear();
+    for (int64_t r = b.r0; r < (int64_t)b.r0 + b.nr; r++) {
+      if (is_heavy(r)) continue;
+      row_tiles(sc, r, [&](int t, int32_t k) {
+        if (sc.np[(size_t)t] == 0 && sc.ns[(size_t)t] == 0) sc.touched.push_back(t);
+        if (fold) { sc.np[(size_t)t] += k / 2; sc.ns[(size_t)t] += k & 1; }
+        else sc.ns[(size_t)t] += k;
+      });
+    }
+    std::sort(sc.touched.begin(), sc.touched.end());
     auto &out = bin_pieces[(size_t)bi];
     out.clear();
     out.reserve(sc.touched.size());
     int64_t n = 0;
-    for (size_t k = 0; k < sc.touched.size(); k++) {
-      find_runs(sc, sc.start[k], sc.start[k + 1]);
-      const PiecePack pk = pack_piece((int64_t)sc.lp.size(), (int64_t)sc.ls.size());
-      out.push_back(Piece{sc.touched[k], sc.start[k + 1] - sc.start[k], pk.groups, pk.products, 0, 0, 0});
+    for (int t : sc.touched) {
+      const PiecePack pk = pack_piece(sc.np[(size_t)t], sc.ns[(size_t)t]);
+      out.push_back(Piece{t, 2 * sc.np[(size_t)t] + sc.ns[(size_t)t], pk.groups, pk.products, 0, 0, 0});
       n += pk.products;
+      sc.np[(size_t)t] = sc.ns[(size_t)t] = 0;
     }
     b.n = (int32_t)n;
   });
+  lap("bins + P1 sizes");
   // P2
   parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
     const int64_t r = heavy_rows_idx[(size_t)hi];
@@ -519,6 +565,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       sc.count[(size_t)t] = 0;
     }
   });
+  lap("P2 heavy pieces");
   // S1: positions are relative to the tile's light run until the run starts are known
   std::vector<int64_t> run_len((size_t)CT, 0), run_plen((size_t)CT, 0), run_start((size_t)CT, 0), run_pstart((size_t)CT, 0), hrel(CT, 0);
   int64_t p_off = 0, n_pieces_total = 0, n_blocks_total = 0;
@@ -581,6 +628,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   if (nnz > 0 && H.stream_len > nnz + nnz / 4 + 4096 + 256ll * CT)
     return false; // padding would cost more than 25 %: keep the stream plan
 
+  lap("S1 S2 positions");
   // P3: value dictionary: <= VDICT distinct bit patterns => the stream carries one-byte codes, <= 16 => four-bit
   // codes.  Code 0 is the all-zero word (padding) unless exactly 16 finite non-zero values fill the four-bit table,
   // in which case padding borrows code 0's value: its products are identity (x) finite == identity.
@@ -631,6 +679,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   }
   const bool coded = !H.vdict.empty();
 
+  lap("P3 dictionary");
   // P4 / P5: fill
   if (coded) {
     H.vdict_used = (int)H.vdict.size();
@@ -728,6 +777,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
       }
     }
   });
+  lap("allocs + P4 light fill");
   parallel_items(n_heavy, 1, NT, [&](int64_t hi, int th) {
     const LongRow &lr = H.heavy[(size_t)hi];
     const int64_t r = lr.row;
@@ -749,6 +799,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     for (int32_t j = rp[r]; j < rp[r + 1]; j++)
       put_entry(sc.pos[(size_t)tile_of(ci[j])]++, j);
   });
+  lap("P5 heavy fill");
   // P6: obase[block] = P position of the first product of the block's 64 stream groups (a group stores 4 products
   // unless its first entry carries the fold flag).  Read back from the flags just written, so the two cannot disagree.
   std::vector<int64_t> ob0((size_t)CT + 1, 0);
@@ -764,6 +815,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     }
     if (pp != run_pstart[(size_t)t] + run_plen[(size_t)t]) ok = false;
   });
+  lap("P6 obase");
   if (!ok) return false;
   // 4. phase-1 work items: <= chunk entries of one tile's light run, or of one tile's heavy run
   //    (cuts are multiples of 64 groups from the run start, so wave boundaries are the ones assumed

@@ -355,6 +355,7 @@ static PiecePack pack_piece(int64_t np, int64_t ns) {
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
+  if (CT > 65535) return false;   // (tile numbers travel as 16-bit values in the builder; 2.1 G columns: shard the matrix)
   const bool fold = opt.fold != 0;
 #ifdef SH_PLAN_EMULATE
   auto t_last = std::chrono::steady_clock::now();

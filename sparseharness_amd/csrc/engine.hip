@@ -352,22 +352,24 @@ static PiecePack pack_piece(int64_t np, int64_t ns) {
   return PiecePack{(int32_t)blocks, (int32_t)sg, (int32_t)(2 * blocks + sg), (int32_t)(4 * (blocks + sg))};
 }
 
+// Phase timers of the plan build and the upload (tools builds only: SH_BUILD_TIMES=1 prints them); lap(nullptr) restarts the clock.
+#ifdef SH_PLAN_EMULATE
+static void lap(const char *what) {
+  static std::chrono::steady_clock::time_point t_last;
+  if (!getenv("SH_BUILD_TIMES")) return;
+  const auto now = std::chrono::steady_clock::now();
+  if (what) fprintf(stderr, "[build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+  t_last = now;
+}
+#else
+static inline void lap(const char *) {}
+#endif
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   if (CT > 65535) return false;   // (tile numbers travel as 16-bit values in the builder; 2.1 G columns: shard the matrix)
   const bool fold = opt.fold != 0;
-#ifdef SH_PLAN_EMULATE
-  auto t_last = std::chrono::steady_clock::now();
-  auto lap = [&](const char *what) {
-    if (!getenv("SH_BUILD_TIMES")) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-    t_last = now;
-  };
-#else
-  auto lap = [](const char *) {};
-#endif
+  lap(nullptr);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
   const int64_t per_tile = std::max(1, opt.heavy_per_tile);
@@ -818,6 +820,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   });
   lap("P6 obase");
   if (!ok) return false;
+  struct AtExit { ~AtExit() { lap("work items"); } } at_exit;
   // 4. phase-1 work items: <= chunk entries of one tile's light run, or of one tile's heavy run
   //    (cuts are multiples of 64 groups from the run start, so wave boundaries are the ones assumed
   //    above).  Workgroups are dealt round-robin over the 8 XCDs
@@ -1171,6 +1174,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
   // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
   TiledHost th;
+  lap(nullptr);
   const bool tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
                      build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th);
   // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
@@ -1242,6 +1246,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       DEV_ARRAY(m->d_tpartial, (const uint32_t *)nullptr, (size_t)th.n_partials * 4, 16);
     }
     HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
+    lap("hipMalloc + H2D of the plan");
   }
 #undef DEV_ARRAY
 #undef HIP_TRY_M

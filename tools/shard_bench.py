@@ -31,6 +31,7 @@ for parts in parts_list:
         r0, r1 = int(bounds[k]), int(bounds[k + 1])
         s_rp, s_ci, s_va = partition.take_rows(rp, ci, va, r0, r1)
         A = eng.upload_csr(r1 - r0, n, s_rp, s_ci, s_va)
+        print(parts, k, A.describe(), file=sys.stderr)
         out_t = torch.zeros(r1 - r0, dtype=torch.float32, device="cuda")
         out = eng.wrap(out_t.data_ptr(), r1 - r0)
         for _ in range(5):

@@ -125,6 +125,9 @@ typedef struct sh_plan_options {
   int32_t or_and_bits;     /* 1: also build the bit-blocked layout that SH_OR_AND_I32 launches then run on (x as a bitmap,
                               4 B per entry, no product array: a BFS iteration moves a third of the bytes); 2: ONLY
                               that layout (the matrix then serves SH_OR_AND_I32 alone)                          [SH_OR_AND_BITS] */
+  int32_t build;           /* where the tiled layout is built: 0 default, 1 on the host (threads above), 2 on the device from
+                              the CSR arrays (sorts and scans; a failed device step falls back to the host builder).
+                              Both produce the same arrays, byte for byte                                    [SH_BUILD=host|device] */
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
@@ -137,6 +140,9 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
                      const int32_t *row_ptr, const int32_t *col_idx, const void *val,
                      const sh_plan_options *opt, sh_csr **out);
 int sh_csr_free(sh_engine *e, sh_csr *m);
+/* Who built the matrix's tiled layout: *where = 0 host, 1 device; note (optional, cap bytes) = why the device builder
+ * was not used although asked for, or empty. */
+int sh_csr_builder(const sh_csr *m, int32_t *where, char *note, int64_t cap);
 int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
 /* Algorithmic bytes of one SpMV over this matrix:
  * 8*nnz + 4*(rows+1) + 4*cols + 4*rows [+ 4*rows if y is read]. */

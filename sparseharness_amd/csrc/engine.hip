@@ -8,6 +8,7 @@
 #include "../../include/sparseharness_hip.h"
 #include "kernels.hip.h"
 #include "bits.hip.h"
+#include "plan_common.h"
 
 #include <hip/hip_runtime.h>
 
@@ -86,6 +87,8 @@ struct sh_csr {
   bool bits_only = false;                     // no other plan was built: only SH_OR_AND_I32 launches are served
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
   uint32_t round = 0;                         // reporting launches so far
+  bool built_on_device = false;               // the tiled layout was built by plan_gpu.hip
+  std::string build_note;                     // why the device builder was not used / fell back (empty: nothing to say)
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
 
@@ -118,56 +121,6 @@ static int fail(sh_engine *e, int code, const char *fmt, ...) {
                   "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r),        \
                   __FILE__, __LINE__);                                          \
   } while (0)
-
-// Host threads for the plan build: the option, else the hardware's, at most 16.
-static int build_threads(const sh_plan_options &opt) {
-  int n = (int)std::thread::hardware_concurrency();
-  if (opt.build_threads > 0) n = opt.build_threads;
-  return std::max(1, std::min(n, 16));
-}
-// fn(item, thread) for every item in [0, n): items are handed out `grain` at a time from an atomic
-// counter (bins and heavy rows differ a lot in size), on `threads` std::threads (no OpenMP: the
-// library lives in processes that already carry an OpenMP runtime of their own)
-template <class F> static void parallel_items(int64_t n, int64_t grain, int threads, F fn) {
-  threads = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (n + grain - 1) / grain));
-  if (threads <= 1) {
-    for (int64_t i = 0; i < n; i++) fn(i, 0);
-    return;
-  }
-  std::atomic<int64_t> next{0};
-  auto worker = [&](int th) {
-    for (;;) {
-      const int64_t i0 = next.fetch_add(grain);
-      if (i0 >= n) return;
-      for (int64_t i = i0; i < std::min(n, i0 + grain); i++) fn(i, th);
-    }
-  };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
-  worker(0);
-  for (auto &t : pool) t.join();
-}
-
-// Small open-addressing set of 4-byte value words with first-come codes (value dictionary of the tiled plan).
-struct ValSet {
-  static constexpr uint32_t VH = 2048, VEMPTY = 0xFFFFFFFFu;
-  std::vector<uint32_t> key, code, list;
-  bool overflow = false;
-  ValSet() : key(VH, 0u), code(VH, VEMPTY) {}
-  static uint32_t hash(uint32_t b) { return (b * 2654435761u) >> 21; }   // 11 bits
-  uint32_t find(uint32_t b) const {   // slot holding b, or the empty slot where it belongs
-    uint32_t h = hash(b);
-    while (code[h] != VEMPTY && key[h] != b) h = (h + 1) & (VH - 1);
-    return h;
-  }
-  void add(uint32_t b) {
-    const uint32_t h = find(b);
-    if (code[h] != VEMPTY) return;
-    if (list.size() == (size_t)VDICT) { overflow = true; return; }
-    key[h] = b; code[h] = (uint32_t)list.size();
-    list.push_back(b);
-  }
-};
 
 extern "C" {
 
@@ -322,48 +275,6 @@ static void build_schedule(int64_t rows, const int32_t *rp, std::vector<int32_t>
 // adds B's products to its own (one DPP move each) and stores 4 products, lane B stores nothing.  A
 // piece is a whole number of groups and yields a multiple of 4 products, so it starts 16-byte
 // aligned in P.
-struct TiledHost {
-  std::vector<RowBin> bins;
-  std::vector<TileChunk> chunks;
-  std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
-  std::vector<uint32_t> tval, gdest, gblk, lrp, obase;   // gblk: per 64 product groups of a bin {piece-start mask lo, hi, pieces started before, 0}
-  std::vector<int32_t> ptab;                      // per (bin, piece): P group index of the piece start - its group index inside the bin
-  std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
-  std::vector<uint32_t> vdict;       // empty = raw values
-  int vdict_used = 0;
-  int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values)
-  std::vector<uint16_t> tcol, pslot;
-  int64_t stream_len = 0, p_len = 0, light_len = 0, heavy_base = 0;   // light_len: light stream entries (padding included); p_len: products in P
-  int64_t light_entries = 0;         // light entries of the matrix (no padding)
-  int32_t n_partials = 0;
-  double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
-};
-
-// How one (bin, tile) piece with np pairs and ns single entries is laid out: pair blocks of two groups (4 pairs
-// each; columns without a pair take a single in A and a padding entry in B), then the remaining singles four to a
-// group (padding entries = padding products at the end).  A piece with pair blocks always has a singles group --
-// all padding if need be -- that the builder puts in FRONT when the piece starts at an odd group index, so that
-// every A lands on an even one.
-struct PiecePack { int32_t blocks, sgroups, groups, products; };
-static PiecePack pack_piece(int64_t np, int64_t ns) {
-  const int64_t blocks = (np + 3) / 4, spare = 4 * blocks - np;
-  int64_t sg = (std::max<int64_t>(0, ns - spare) + 3) / 4;
-  if (blocks > 0 && sg == 0) sg = 1;
-  return PiecePack{(int32_t)blocks, (int32_t)sg, (int32_t)(2 * blocks + sg), (int32_t)(4 * (blocks + sg))};
-}
-
-// Phase timers of the plan build and the upload (tools builds only: SH_BUILD_TIMES=1 prints them); lap(nullptr) restarts the clock.
-#ifdef SH_PLAN_EMULATE
-static void lap(const char *what) {
-  static std::chrono::steady_clock::time_point t_last;
-  if (!getenv("SH_BUILD_TIMES")) return;
-  const auto now = std::chrono::steady_clock::now();
-  if (what) fprintf(stderr, "[build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-  t_last = now;
-}
-#else
-static inline void lap(const char *) {}
-#endif
 static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int32_t *rp,
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
@@ -639,7 +550,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   ValSet dict;
   {
     bool coded = opt.value_coding >= 0;
-    const bool bytes_only = opt.value_coding == 8;
     if (coded) {
       std::vector<ValSet> part((size_t)NT);
       parallel_items((nnz + 65535) / 65536, 4, NT, [&](int64_t blk, int th) {
@@ -655,27 +565,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         for (uint32_t b : vs.list) all.add(b);
       }
       std::vector<uint32_t> words(all.list);
-      std::sort(words.begin(), words.end());
-      const bool has_zero = !words.empty() && words[0] == 0u;
-      bool all_finite = true;   // as floats: padding may then carry ANY code (identity (x) finite == identity in all four semirings)
-      for (uint32_t b : words) all_finite = all_finite && ((b >> 23) & 0xFFu) != 0xFFu;
-      dict = ValSet();
-      if (all.overflow || words.size() > (size_t)VDICT) {
-        dict.overflow = true;
-      } else if (!bytes_only && words.size() + (has_zero ? 0 : 1) <= 16) {
-        H.code_bits = 4;
-        dict.add(0u);                      // code 0 = the all-zero word: padding
-        for (uint32_t b : words) dict.add(b);
-      } else if (!bytes_only && words.size() == 16 && all_finite) {
-        H.code_bits = 4;                   // 16 finite values and no zero among them: padding borrows code 0's value
-        for (uint32_t b : words) dict.add(b);
-      } else if (words.size() + (has_zero ? 0 : 1) <= (size_t)VDICT) {
-        H.code_bits = 8;
-        dict.add(0u);
-        for (uint32_t b : words) dict.add(b);
-      } else {
-        dict.overflow = true;
-      }
+      decide_value_coding(words, all.overflow, opt, H.code_bits, dict);
       coded = !dict.overflow;
     }
     if (coded) H.vdict = dict.list;
@@ -820,100 +710,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   });
   lap("P6 obase");
   if (!ok) return false;
-  struct AtExit { ~AtExit() { lap("work items"); } } at_exit;
-  // 4. phase-1 work items: <= chunk entries of one tile's light run, or of one tile's heavy run
-  //    (cuts are multiples of 64 groups from the run start, so wave boundaries are the ones assumed
-  //    above).  Workgroups are dealt round-robin over the 8 XCDs
-  //    (blocks b and b+8 share one, MI355X_MICROARCH.md), so chunk position p holds a chunk of a tile
-  //    with tile % 8 == p % 8: every XCD then stages only its own eighth of x through its L2 instead
-  //    of all of it (speed only; correctness does not depend on placement).
-  // Entries per work item.  Every item stages a 128 KiB x tile (~2 us of a ~9 us item), so fewer, larger items cost
-  // less in total, but the launch ends with its slowest workgroup and a CU needs a handful of items to even out.
-  // Measured (equal cuts, 10 M / 200 M matrix and its 1/2, 1/4, 1/8 shards; profiles/r02_chunk_size_vs_shard_size.log):
-  // 64 K entries is best while the launch still has >= 6 items per CU (-3 % at full size), 48 K below that
-  // (-7 % on a 1/8 shard against 32 K).  opt.chunk > 0 overrides.
-  auto items_at = [&](int64_t c) {
-    int64_t n = 0;
-    for (int t = 0; t < CT; t++) n += (run_len[(size_t)t] + c - 1) / c + (hrel[(size_t)t] + c - 1) / c;
-    return n;
-  };
-  // Round 3 (pair folding, same box): 48 K 0.453, 64 K 0.443, 96 K 0.448, 128 K 0.437 ms at full size -> 128 K under the same rule.
-  const int64_t enough = 6ll * std::max(n_cus, 1);
-  int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(131072) >= enough ? 131072 : (items_at(65536) >= enough ? 65536 : 49152));
-  chunk = std::max<int64_t>(1024, chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips
-  const bool xcd_order = opt.xcd_order != 0;
-  // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).
-  // Skewed columns (a graph's hub columns fill a few tiles) would leave one XCD with most of the work while
-  // the workgroups dealt to the other seven return at once, so tiles are handed out by weight, heaviest first,
-  // to the least loaded XCD, and a tile heavier than an XCD's fair share is cut across several XCDs (home_of()
-  // then moves on to the next least loaded XCD after a fair share's worth of the tile's chunks).
-  // tile_segs[t]: (entries of the tile up to which the XCD applies, XCD), ascending
-  std::vector<std::vector<std::pair<int64_t, int>>> tile_segs((size_t)CT);
-  {
-    std::vector<int64_t> weight((size_t)CT, 0);
-    for (int t = 0; t < CT; t++) weight[(size_t)t] = hrel[(size_t)t] + run_len[(size_t)t];
-    const int64_t fair = std::max<int64_t>(chunk, H.stream_len / 8);
-    bool uniform = true;   // no tile far above the mean: keep the plain tile % 8 order
-    for (int t = 0; t < CT; t++) uniform = uniform && weight[(size_t)t] * CT <= 2 * H.stream_len + 2 * chunk * CT;
-    std::vector<int> order((size_t)CT);
-    for (int t = 0; t < CT; t++) order[(size_t)t] = t;
-    if (!uniform)
-      std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return weight[(size_t)a2] > weight[(size_t)b2]; });
-    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t : order) {
-      int64_t done = 0;
-      do {
-        int c = t & 7;
-        if (!uniform)
-          for (int k = 0; k < 8; k++) if (load[k] < load[c]) c = k;
-        const int64_t take = uniform ? weight[(size_t)t] : std::min(weight[(size_t)t] - done, fair);
-        load[c] += take;
-        done += take;
-        tile_segs[(size_t)t].emplace_back(done, c);
-      } while (done < weight[(size_t)t]);
-    }
-  }
-  // XCD list of the chunk that starts `before` entries into tile t
-  auto home_of = [&](int t, int64_t before) -> int {
-    if (!xcd_order) return 0;
-    for (const auto &sg : tile_segs[(size_t)t])
-      if (before < sg.first) return sg.second;
-    return tile_segs[(size_t)t].empty() ? (t & 7) : tile_segs[(size_t)t].back().second;
-  };
-  // cut one run into chunks
-  std::vector<TileChunk> per_xcd[8];
-  // (Guided sizes -- the first 60..75 % of every run in items of 128..256 K entries, the rest in items a quarter that
-  // size handed out behind all the big ones -- were measured and lost: 0.446..0.454 vs 0.435 ms same box,
-  // profiles/r03_ab_guided_chunk_sizes.log; plain 128 K items: 0.431.)
-  auto cut_run = [&](int t, int64_t start, int64_t len, bool heavy) {
-    // equal cuts: a run of 56 K entries becomes 2 x 28 K, not 32 K + 24 K (the launch ends with its slowest workgroup)
-    const int64_t pieces = (len + chunk - 1) / chunk;
-    const int64_t cut = pieces > 0 ? std::min<int64_t>(chunk, ((len + pieces - 1) / pieces + 64 * HSTRIP - 1) & ~int64_t(64 * HSTRIP - 1)) : chunk;
-    for (int64_t s0 = start; s0 < start + len; s0 += cut) {
-      const int64_t e0 = std::min<int64_t>(s0 + cut, start + len);
-      // light chunks: ob0 = the chunk's first block of obase[] (cuts are multiples of 256 entries from the run start)
-      TileChunk ch{t, (int32_t)s0, (int32_t)e0, (int32_t)(heavy ? start : e0),
-                   (int32_t)(heavy ? H.heavy_base : 0), (int32_t)(heavy ? 0 : ob0[(size_t)t] + (s0 - start) / 256), 0, 0};
-      per_xcd[home_of(t, (heavy ? run_len[(size_t)t] : 0) + (s0 - start))].push_back(ch);
-    }
-  };
-  // ONE phase-1 launch, tile by tile -- a tile's light chunks, then its heavy chunks -- so that memory-bound
-  // light chunks and the ALU-heavier heavy chunks are in flight together.
-  for (int t = 0; t < CT; t++) {
-    cut_run(t, run_start[(size_t)t], run_len[(size_t)t], false);
-    cut_run(t, heavy_start[(size_t)t], hrel[(size_t)t], true);
-  }
-  // per-XCD lists interleaved so that position p holds a chunk of XCD p % 8 (empty fillers where a list is short)
-  {
-    size_t longest = 0;
-    for (auto &v : per_xcd) longest = std::max(longest, v.size());
-    if (!xcd_order)
-      H.chunks.insert(H.chunks.end(), per_xcd[0].begin(), per_xcd[0].end());
-    else
-      for (size_t i = 0; i < longest; i++)
-        for (int c = 0; c < 8; c++)
-          H.chunks.push_back(i < per_xcd[c].size() ? per_xcd[c][i] : TileChunk{0, 0, 0, 0, 0, 0, 0, 0});   // empty filler
-  }
+  cut_work_items(CT, run_start, run_len, heavy_start, hrel, ob0, opt, n_cus, H);
+  lap("work items");
   return true;
 }
 
@@ -1073,6 +871,11 @@ int sh_plan_row_work(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row
   return SH_OK;
 }
 
+// sh_plan_options::build == 0: the tiled layout is built on the device from this many entries on (a 200 M-entry matrix:
+// 0.11 s instead of 0.72 s per upload, profiles/r03_build_probe.json); below, the host builder's microseconds beat the
+// device builder's ~40 allocations and launches.
+static constexpr int64_t DEVICE_BUILD_MIN_NNZ = 1 << 20;
+
 void sh_plan_options_default(sh_plan_options *o) {
   if (!o) return;
   memset(o, 0, sizeof *o);
@@ -1097,6 +900,7 @@ void sh_plan_options_from_env(sh_plan_options *o) {
   if (const char *v = getenv("SH_XCD_ORDER")) o->xcd_order = v[0] != '0';
   if (const char *v = getenv("SH_FOLD")) o->fold = v[0] != '0';
   num("SH_OR_AND_BITS", o->or_and_bits);
+  if (const char *v = getenv("SH_BUILD")) o->build = !strcmp(v, "host") ? 1 : ((!strcmp(v, "device") || !strcmp(v, "gpu")) ? 2 : 0);
 }
 
 int sh_csr_upload(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
@@ -1174,23 +978,13 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
   // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
   TiledHost th;
+  TiledDevArrays td;   // the big arrays when the layout was built on the device
+  struct TdGuard { TiledDevArrays &t; ~TdGuard() { t.release(); } } td_guard{td};   // (whatever was not adopted below)
   lap(nullptr);
-  const bool tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0 &&
-                     build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th);
-  // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
-  // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
-  const bool tune = tiled && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5;
-  m->plan = tiled ? PLAN_TILED : PLAN_STREAM;
-  acct = &m->stream_bytes;
-  if (!tiled || tune) {
-    std::vector<int32_t> pairs;
-    std::vector<LongSeg> segs;
-    std::vector<LongRow> longs;
-    build_schedule(rows, row_ptr, pairs, segs, longs);
-    m->n_stream = (int32_t)(pairs.size() / 2);
-    m->n_segs = (int32_t)segs.size();
-    m->n_long = (int32_t)longs.size();
-    const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;   // the tail is padded so that 16-byte loads at the end stay in bounds
+  const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;   // the tail is padded so that 16-byte loads at the end stay in bounds
+  bool csr_on_device = false;
+  auto upload_csr_arrays = [&]() -> int {   // row_ptr / col_idx / val as they are: plan A's arrays, and the device builder's input
+    acct = &m->stream_bytes;
     DEV_ARRAY(m->d_row_ptr, row_ptr, (rows + 1) * 4, 0);
     DEV_ARRAY(m->d_col, (const int32_t *)nullptr, padded * 4, 0);
     DEV_ARRAY(m->d_val, (const uint32_t *)nullptr, padded * 4, 0);
@@ -1200,6 +994,47 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       HIP_TRY_M(hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, e->stream));
       HIP_TRY_M(hipMemcpyAsync(m->d_val, val, nnz * 4, hipMemcpyHostToDevice, e->stream));
     }
+    csr_on_device = true;
+    return SH_OK;
+  };
+  // Where the tiled layout is built (sh_plan_options::build): on the device from the CSR arrays (plan_gpu.hip; the
+  // default), or by the host builder below -- also the fallback when a device step fails.  Same bytes either way.
+  bool want_tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0;
+  bool tiled = false;
+  if (want_tiled && (opt.build == 2 || (opt.build == 0 && nnz >= DEVICE_BUILD_MIN_NNZ))) {
+    if (const int rc = upload_csr_arrays()) return rc;
+    lap("H2D of the CSR arrays");
+    std::string why;
+    const int g = build_tiled_plan_gpu(e->stream, rows, cols, nnz, row_ptr, m->d_row_ptr, m->d_col, m->d_val, opt, e->n_cus, th, td, why);
+    lap("device build");
+    if (g == 1) {
+      tiled = true;
+      m->built_on_device = true;
+    } else {
+      td.release();
+      th = TiledHost();
+      m->build_note = why;
+      if (g == 0) want_tiled = false;   // the layout does not suit this matrix: the host builder would refuse as well
+    }
+  }
+  if (want_tiled && !tiled)
+    tiled = build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, th);
+  // (only worth timing when the bins touch few of the column tiles, i.e. the columns are local: with
+  // scattered columns -- every bin has a piece in nearly every tile -- plan A is several times slower)
+  const bool tune = tiled && opt.plan == 0 && opt.autotune && th.tile_fill < 0.5;
+  m->plan = tiled ? PLAN_TILED : PLAN_STREAM;
+  // The CSR arrays (8 B per entry) stay on the device only for plan A, or while both plans are timed.
+  if (!tiled || tune) {
+    std::vector<int32_t> pairs;
+    std::vector<LongSeg> segs;
+    std::vector<LongRow> longs;
+    build_schedule(rows, row_ptr, pairs, segs, longs);
+    m->n_stream = (int32_t)(pairs.size() / 2);
+    m->n_segs = (int32_t)segs.size();
+    m->n_long = (int32_t)longs.size();
+    if (!csr_on_device)
+      if (const int rc = upload_csr_arrays()) return rc;
+    acct = &m->stream_bytes;
     // The kernel reads blk_row[b] and blk_row[b+1]; with long rows in between the
     // blocks are not contiguous, so upload the pair list and index it as 2*b.
     DEV_ARRAY(m->d_blk_row, pairs.data(), pairs.size() * 4, 8);
@@ -1209,6 +1044,11 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       DEV_ARRAY(m->d_partial, (const uint32_t *)nullptr, segs.size() * 4, 0);
     }
     HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
+  } else if (csr_on_device) {
+    HIP_TRY_M(hipStreamSynchronize(e->stream));
+    (void)hipFree(m->d_row_ptr); (void)hipFree(m->d_col); (void)hipFree(m->d_val);
+    m->d_row_ptr = nullptr; m->d_col = nullptr; m->d_val = nullptr;
+    m->stream_bytes = 0;
   }
   acct = &m->tiled_bytes;
   if (tiled) {
@@ -1224,23 +1064,31 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     for (const RowBin &b : th.bins) m->bin_r0.push_back(b.r0);
     DEV_ARRAY(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), 0);
     DEV_ARRAY(m->d_chunks, th.chunks.data(), th.chunks.size() * sizeof(TileChunk), 0);
+    // the big arrays: already on the device (device builder) or uploaded from the host builder's vectors
+#define PLAN_ARRAY(ptr, dev, host_vec, elem_bytes, slack)                                                       \
+  do {                                                                                                        \
+    if (m->built_on_device) { (ptr) = (dev); (dev) = nullptr; *acct += (size_t)(td_n) * (elem_bytes) + (slack); } \
+    else DEV_ARRAY(ptr, (host_vec).data(), (host_vec).size() * (elem_bytes), slack);                          \
+  } while (0)
+    size_t td_n = 0;
     if (!th.vdict.empty()) {
       m->n_vdict = (int)th.vdict.size();
       m->n_vdict_used = th.vdict_used;
       m->code_bits = th.code_bits;
-      DEV_ARRAY(m->d_tcode, th.tcode.data(), th.tcode.size(), 64);
+      td_n = td.n_tcode; PLAN_ARRAY(m->d_tcode, td.tcode, th.tcode, 1, SLACK_TCODE);
       DEV_ARRAY(m->d_vdict, th.vdict.data(), th.vdict.size() * 4, 0);
     } else {
-      DEV_ARRAY(m->d_tval, th.tval.data(), th.tval.size() * 4, 16);
+      td_n = td.n_tval; PLAN_ARRAY(m->d_tval, td.tval, th.tval, 4, SLACK_WIDE);
     }
-    DEV_ARRAY(m->d_tcol, th.tcol.data(), th.tcol.size() * 2, 16);
-    DEV_ARRAY(m->d_gdest, th.gdest.data(), th.gdest.size() * 4, 16);
-    DEV_ARRAY(m->d_gblk, th.gblk.data(), th.gblk.size() * 4, 16);
-    DEV_ARRAY(m->d_ptab, th.ptab.data(), th.ptab.size() * 4, 16);
-    DEV_ARRAY(m->d_pslot, th.pslot.data(), th.pslot.size() * 2, 16);
-    DEV_ARRAY(m->d_obase, th.obase.data(), th.obase.size() * 4, 16);
+    td_n = td.n_tcol; PLAN_ARRAY(m->d_tcol, td.tcol, th.tcol, 2, SLACK_WIDE);
+    td_n = td.n_gdest; PLAN_ARRAY(m->d_gdest, td.gdest, th.gdest, 4, SLACK_WIDE);
+    td_n = td.n_gblk; PLAN_ARRAY(m->d_gblk, td.gblk, th.gblk, 4, SLACK_WIDE);
+    td_n = td.n_ptab; PLAN_ARRAY(m->d_ptab, td.ptab, th.ptab, 4, SLACK_WIDE);
+    td_n = td.n_pslot; PLAN_ARRAY(m->d_pslot, td.pslot, th.pslot, 2, SLACK_WIDE);
+    td_n = td.n_obase; PLAN_ARRAY(m->d_obase, td.obase, th.obase, 4, SLACK_WIDE);
     DEV_ARRAY(m->d_P, (const uint32_t *)nullptr, (size_t)std::max<int64_t>(m->p_len, 4) * 4, 16);
-    DEV_ARRAY(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, 0);
+    if (m->built_on_device) { m->d_lrp = (int32_t *)td.lrp; td.lrp = nullptr; *acct += td.n_lrp * 4; }
+    else DEV_ARRAY(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, 0);
     if (m->n_tlong) {
       DEV_ARRAY(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), 0);
       DEV_ARRAY(m->d_tpartial, (const uint32_t *)nullptr, (size_t)th.n_partials * 4, 16);
@@ -1248,6 +1096,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at return
     lap("hipMalloc + H2D of the plan");
   }
+#undef PLAN_ARRAY
 #undef DEV_ARRAY
 #undef HIP_TRY_M
   if (tune)
@@ -1277,6 +1126,14 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
     if (p) (void)hipFree(p);
   if (m->h_done) (void)hipHostFree(m->h_done);
   delete m;
+  return SH_OK;
+}
+
+int sh_csr_builder(const sh_csr *m, int32_t *where, char *note, int64_t cap) {
+  if (!m)
+    return SH_EINVAL;
+  if (where) *where = m->built_on_device ? 1 : 0;
+  if (note && cap > 0) snprintf(note, (size_t)cap, "%s", m->build_note.c_str());
   return SH_OK;
 }
 
@@ -1942,4 +1799,112 @@ extern "C" int sh_debug_emulate_plan(int64_t rows, int64_t cols, int64_t nnz, co
   if (semiring == 2) return emulate<HOrAnd>(H, rows, cols, (const uint32_t *)x, (uint32_t *)y, stats);
   return -2;
 }
+// Builds the tiled layout of one matrix twice -- host builder and device builder -- and compares every array.
+// Returns the number of arrays (or scalars) that differ, 0 = identical byte for byte; -1: the host builder refused the
+// matrix, -2: the device builder refused or failed (report says why), -3: a HIP call of this function failed.
+// report (cap bytes) gets one line per difference: the array, the first differing element, both values.
+extern "C" int sh_debug_compare_builds(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx,
+                                       const void *val, const sh_plan_options *opt_p, char *report, int64_t cap) {
+  sh_plan_options opt;
+  if (opt_p) opt = *opt_p; else sh_plan_options_default(&opt);
+  std::string rep;
+  auto finish = [&](int rc) { if (report && cap > 0) snprintf(report, (size_t)cap, "%s", rep.c_str()); return rc; };
+  if (!e || nnz <= 0) { rep = "bad argument"; return finish(-3); }
+  if (hipSetDevice(e->device) != hipSuccess) { rep = "hipSetDevice"; return finish(-3); }
+  TiledHost hh, hg;
+  TiledDevArrays td;
+  struct Guard { TiledDevArrays &t; std::vector<void *> p; ~Guard() { t.release(); for (void *q : p) (void)hipFree(q); } } guard{td, {}};
+  if (!build_tiled_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, e->n_cus, hh)) { rep = "host builder refused"; return finish(-1); }
+  int32_t *d_rp = nullptr, *d_ci = nullptr;
+  uint32_t *d_val = nullptr;
+  if (hipMalloc((void **)&d_rp, (size_t)(rows + 1) * 4) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_rp);
+  if (hipMalloc((void **)&d_ci, (size_t)nnz * 4 + 32) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_ci);
+  if (hipMalloc((void **)&d_val, (size_t)nnz * 4 + 32) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_val);
+  if (hipMemcpy(d_rp, row_ptr, (size_t)(rows + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_ci, col_idx, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_val, val, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess) { rep = "hipMemcpy"; return finish(-3); }
+  std::string why;
+  const int g = build_tiled_plan_gpu(e->stream, rows, cols, nnz, row_ptr, d_rp, d_ci, d_val, opt, e->n_cus, hg, td, why);
+  if (g != 1) { rep = "device builder: " + why; return finish(-2); }
+  int diffs = 0;
+  char line[256];
+  auto scalar = [&](const char *name, long long a, long long b) {
+    if (a != b) { snprintf(line, sizeof line, "%s: host %lld device %lld\n", name, a, b); rep += line; diffs++; }
+  };
+  scalar("stream_len", hh.stream_len, hg.stream_len); scalar("p_len", hh.p_len, hg.p_len); scalar("light_len", hh.light_len, hg.light_len);
+  scalar("heavy_base", hh.heavy_base, hg.heavy_base); scalar("light_entries", hh.light_entries, hg.light_entries);
+  scalar("n_partials", hh.n_partials, hg.n_partials); scalar("code_bits", hh.code_bits, hg.code_bits); scalar("vdict_used", hh.vdict_used, hg.vdict_used);
+  scalar("n_bins", (long long)hh.bins.size(), (long long)hg.bins.size()); scalar("n_chunks", (long long)hh.chunks.size(), (long long)hg.chunks.size());
+  scalar("n_heavy", (long long)hh.heavy.size(), (long long)hg.heavy.size());
+  scalar("tile_fill*1e6", (long long)(hh.tile_fill * 1e6), (long long)(hg.tile_fill * 1e6));
+  auto host_bytes = [&](const char *name, const void *a, size_t na, const void *b, size_t nb, size_t elem) {
+    if (na != nb) { snprintf(line, sizeof line, "%s: %zu vs %zu bytes\n", name, na, nb); rep += line; diffs++; return; }
+    if (na && memcmp(a, b, na) != 0) {
+      size_t k = 0;
+      while (k < na && ((const uint8_t *)a)[k] == ((const uint8_t *)b)[k]) k++;
+      size_t ndiff = 0;
+      for (size_t q = 0; q + elem <= na; q += elem) if (memcmp((const uint8_t *)a + q, (const uint8_t *)b + q, elem) != 0) ndiff++;
+      const size_t el = k / elem;
+      unsigned long long va = 0, vb = 0;
+      memcpy(&va, (const uint8_t *)a + el * elem, std::min<size_t>(elem, 8)); memcpy(&vb, (const uint8_t *)b + el * elem, std::min<size_t>(elem, 8));
+      snprintf(line, sizeof line, "%s: %zu of %zu elements differ, first at %zu: host 0x%llx device 0x%llx\n", name, ndiff, na / elem, el, va, vb);
+      rep += line; diffs++;
+    }
+  };
+  host_bytes("bins", hh.bins.data(), hh.bins.size() * sizeof(RowBin), hg.bins.data(), hg.bins.size() * sizeof(RowBin), sizeof(RowBin));
+  host_bytes("chunks", hh.chunks.data(), hh.chunks.size() * sizeof(TileChunk), hg.chunks.data(), hg.chunks.size() * sizeof(TileChunk), sizeof(TileChunk));
+  host_bytes("heavy", hh.heavy.data(), hh.heavy.size() * sizeof(LongRow), hg.heavy.data(), hg.heavy.size() * sizeof(LongRow), sizeof(LongRow));
+  host_bytes("vdict", hh.vdict.data(), hh.vdict.size() * 4, hg.vdict.data(), hg.vdict.size() * 4, 4);
+  bool hip_ok = true;
+  auto dev_bytes = [&](const char *name, const void *host, size_t nbytes_host, const void *dev, size_t n_dev, size_t elem) {
+    std::vector<uint8_t> tmp(n_dev * elem);
+    if (n_dev && hipMemcpy(tmp.data(), dev, n_dev * elem, hipMemcpyDeviceToHost) != hipSuccess) { hip_ok = false; return; }
+    host_bytes(name, host, nbytes_host, tmp.data(), n_dev * elem, elem);
+  };
+  dev_bytes("lrp", hh.lrp.data(), hh.lrp.size() * 4, td.lrp, td.n_lrp, 4);
+  dev_bytes("tcol", hh.tcol.data(), hh.tcol.size() * 2, td.tcol, td.n_tcol, 2);
+  dev_bytes("tcode", hh.tcode.data(), hh.tcode.size(), td.tcode, td.n_tcode, 1);
+  dev_bytes("tval", hh.tval.data(), hh.tval.size() * 4, td.tval, td.n_tval, 4);
+  dev_bytes("gdest", hh.gdest.data(), hh.gdest.size() * 4, td.gdest, td.n_gdest, 4);
+  dev_bytes("pslot", hh.pslot.data(), hh.pslot.size() * 2, td.pslot, td.n_pslot, 2);
+  dev_bytes("gblk", hh.gblk.data(), hh.gblk.size() * 4, td.gblk, td.n_gblk, 4);
+  dev_bytes("ptab", hh.ptab.data(), hh.ptab.size() * 4, td.ptab, td.n_ptab, 4);
+  dev_bytes("obase", hh.obase.data(), hh.obase.size() * 4, td.obase, td.n_obase, 4);
+  if (!hip_ok) { rep += "hipMemcpy (download) failed\n"; return finish(-3); }
+  return finish(diffs);
+}
+// Placement experiments (tools/placement_probe.py): move one array of the tiled plan to a fresh allocation (hold != 0:
+// the old one is kept allocated -- and leaked until process exit -- so that the new one cannot land in the same place),
+// return its new address.  which: 0 P, 1 tcol, 2 tcode / tval, 3 pslot, 4 gblk, 5 ptab, 6 obase, 7 lrp.
+// align_log2 > 21: the new place is the first address aligned to 2^align_log2 inside an allocation that much larger (the
+// base is leaked: experiments only).
+extern "C" int sh_debug_move_array(sh_engine *e, sh_csr *m, int which, int hold, int align_log2, uint64_t *address) {
+  if (!e || !m || m->plan != PLAN_TILED) return SH_EINVAL;
+  if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return SH_EHIP;
+  void **slot = nullptr;
+  size_t bytes = 0;
+  const bool coded = m->n_vdict != 0;
+  switch (which) {
+    case 0: slot = (void **)&m->d_P; bytes = (size_t)std::max<int64_t>(m->p_len, 4) * 4 + 16; break;
+    case 1: slot = (void **)&m->d_tcol; bytes = (size_t)m->stream_len * 2 + 16; break;
+    case 2: if (coded) { slot = (void **)&m->d_tcode; bytes = (size_t)(m->code_bits == 4 ? m->stream_len / 2 : m->stream_len) + 64; }
+            else { slot = (void **)&m->d_tval; bytes = (size_t)m->stream_len * 4 + 16; }
+            break;
+    case 3: slot = (void **)&m->d_pslot; bytes = (size_t)m->p_len * 2 + 16; break;
+    default: return SH_EINVAL;
+  }
+  void *fresh = nullptr;
+  const size_t align = align_log2 > 21 ? (size_t)1 << align_log2 : 0;
+  if (hipMalloc(&fresh, bytes + align) != hipSuccess) return SH_ENOMEM;
+  if (align) fresh = (void *)(((uintptr_t)fresh + align - 1) & ~(uintptr_t)(align - 1));
+  if (hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return SH_EHIP;
+  if (!hold) (void)hipFree(*slot);
+  *slot = fresh;
+  if (address) *address = (uint64_t)(uintptr_t)fresh;
+  return SH_OK;
+}
 #endif
+

@@ -131,7 +131,7 @@ __device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
 
 // After launches that do not report by themselves (CSR-stream plan, a matrix of heavy rows only): one more tiny
 // launch on the same stream -- every row is written by then -- completes the round of every piece.
-__global__ void report_all_pieces(StepDev st) {
+static __global__ void report_all_pieces(StepDev st) {
   // (launched behind the kernels that wrote the rows: a kernel boundary, their write-through stores are complete)
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int c = 0; c < st.n_pieces; c++) {

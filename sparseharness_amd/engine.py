@@ -94,6 +94,12 @@ class CsrMatrix:
         self.engine._chk(abi.load().sh_csr_footprint(self.h, C.byref(b)))
         return b.value
 
+    def builder(self):
+        """("host" | "device", note): who built the tiled layout, and why the device builder was not used if asked for."""
+        w, note = C.c_int32(), C.create_string_buffer(256)
+        self.engine._chk(abi.load().sh_csr_builder(self.h, C.byref(w), note, len(note)))
+        return ("device" if w.value else "host"), note.value.decode()
+
     def free(self):
         if self.h is not None:
             abi.load().sh_csr_free(self.engine.h, self.h)

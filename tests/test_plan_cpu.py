@@ -20,11 +20,7 @@ LIB = os.path.join(ROOT, "sparseharness_amd", "variants", "emulate.so")
 
 @pytest.fixture(scope="module")
 def emu():
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "bits.hip.h", "semiring.hip.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in src):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
-                               "-ffp-contract=off", "-Wno-unused-function", "-DSH_PLAN_EMULATE", src[0], "-o", LIB])
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emulate"])   # (rebuilds only when a source is newer)
     lib = C.CDLL(LIB)
     lib.sh_plan_options_default.argtypes = [C.POINTER(abi.sh_plan_options)]
     lib.sh_debug_emulate_plan.restype = C.c_int

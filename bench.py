@@ -324,7 +324,7 @@ def main():
         "ms_per_step_raw_values": None if ablation is None else ablation["ms_per_step"],
         "ablation_raw_values": ablation,
         "parity": parity,
-        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": layout},
+        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": layout, "built_on": A.builder()[0]},
         "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,
     }
     if rehearsal:

@@ -37,7 +37,7 @@ struct BitsItem { int32_t rr, ct, s, e, sub0, sub1, soff, pad; };
 
 // x -> bitmap: bit c of xbits = (x[c] != 0).  A thread takes 4 consecutive columns (one 16-byte load), eight
 // neighbouring lanes OR their nibbles into one 32-bit word (three xor-shuffles), the first of them stores it.
-__global__ __launch_bounds__(256) void bits_pack_x(const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ xbits,
+static __global__ __launch_bounds__(256) void bits_pack_x(const uint32_t *__restrict__ x, int32_t cols, uint32_t *__restrict__ xbits,
                                                    int64_t n_words32, const int32_t *gate) {
   if (gate != nullptr && *gate == 0) return;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void bits_pack_x(const uint32_t *__restrict__ 
   if ((lane & 7) == 0) xbits[t >> 3] = w;
 }
 
-__global__ __launch_bounds__(BITS_TBS) void bits_blocks(const BitsItem *__restrict__ items, const uint32_t *__restrict__ ent,
+static __global__ __launch_bounds__(BITS_TBS) void bits_blocks(const BitsItem *__restrict__ items, const uint32_t *__restrict__ ent,
                                                         const int32_t *__restrict__ bsub, const uint32_t *__restrict__ xbits,
                                                         uint32_t *__restrict__ partial, const int32_t *gate) {
   __shared__ uint32_t xs[BITS_BC / 32];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BITS_TBS) void bits_blocks(const BitsItem *__restri
 // word r >> 5 -- so that y / the previous vector / out are accessed 256 bytes at a time.
 constexpr int BITS_FIN_ROWS = 2048 * 4;   // rows per 256-thread workgroup
 static_assert(BITS_BR % BITS_FIN_ROWS == 0, "a workgroup's rows lie in one row range");
-__global__ __launch_bounds__(256) void bits_finish(const int32_t *__restrict__ rr_item0, const uint32_t *__restrict__ partial,
+static __global__ __launch_bounds__(256) void bits_finish(const int32_t *__restrict__ rr_item0, const uint32_t *__restrict__ partial,
                                                    int32_t rows, const uint32_t *__restrict__ y, int32_t alpha, int32_t beta,
                                                    int use_y_i, uint32_t *__restrict__ out, StepDev st) {
   if (gate_closed(st)) return;

@@ -716,13 +716,6 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
 }
 
 // ---- the (or,and) semiring on bits (see bits.hip.h) -----------------------
-struct BitsHost {
-  std::vector<BitsItem> items;
-  std::vector<uint32_t> ent;
-  std::vector<int32_t> bsub, rr_item0;
-  int32_t n_rr = 0, n_ct = 0;
-  int64_t entries = 0;   // entries with a non-zero value and a column in range
-};
 // Entries of row range rr / column block ct, ordered by row (the CSR walk is row-major), every 8192-row sub-range
 // padded to a multiple of 8 entries with copies of its last entry; blocks with more than `max_item` entries are cut
 // at sub-range boundaries into several work items.
@@ -741,10 +734,8 @@ static bool build_bits_plan(int64_t rows, int64_t cols, int64_t nnz, const int32
       for (int32_t j = rp[r]; j < rp[r + 1]; j++)
         if (live(j)) cnt[(size_t)cell_of(r, ci[j])]++;
   });
-  int64_t pos = 0;
-  for (int64_t k = 0; k < ncell; k++) { start[(size_t)k] = pos; pos += (cnt[(size_t)k] + 7) & ~int64_t(7); H.entries += cnt[(size_t)k]; }
-  start[(size_t)ncell] = pos;
-  if (pos > INT32_MAX - 8) return false;
+  if (!bits_starts_and_items(H, cnt, start)) return false;
+  const int64_t pos = start[(size_t)ncell];
   H.ent.assign((size_t)pos + 8, 0u);
   parallel_items(H.n_rr, 1, NT, [&](int64_t rr, int) {
     std::vector<int64_t> cur((size_t)H.n_ct * BITS_NSUB);
@@ -760,26 +751,7 @@ static bool build_bits_plan(int64_t rows, int64_t cols, int64_t nnz, const int32
       for (int64_t q = cur[(size_t)k]; q < end; q++) H.ent[(size_t)q] = H.ent[(size_t)cur[(size_t)k] - 1];
     }
   });
-  const int64_t max_item = 1 << 20;
-  H.rr_item0.assign((size_t)H.n_rr + 1, 0);
-  for (int32_t rr = 0; rr < H.n_rr; rr++) {
-    H.rr_item0[(size_t)rr] = (int32_t)H.items.size();
-    for (int32_t ct = 0; ct < H.n_ct; ct++) {
-      const int64_t c0 = ((int64_t)rr * H.n_ct + ct) * BITS_NSUB;
-      if (start[(size_t)(c0 + BITS_NSUB)] == start[(size_t)c0]) continue;   // an empty block
-      for (int sub0 = 0; sub0 < BITS_NSUB;) {
-        int sub1 = sub0 + 1;
-        while (sub1 < BITS_NSUB && start[(size_t)(c0 + sub1 + 1)] - start[(size_t)(c0 + sub0)] <= max_item) sub1++;
-        if (start[(size_t)(c0 + sub1)] > start[(size_t)(c0 + sub0)]) {
-          BitsItem it{rr, ct, (int32_t)start[(size_t)(c0 + sub0)], (int32_t)start[(size_t)(c0 + sub1)], sub0, sub1, (int32_t)H.bsub.size(), 0};
-          for (int k = sub0; k <= sub1; k++) H.bsub.push_back((int32_t)start[(size_t)(c0 + k)]);
-          H.items.push_back(it);
-        }
-        sub0 = sub1;
-      }
-    }
-  }
-  H.rr_item0[(size_t)H.n_rr] = (int32_t)H.items.size();
+  H.ent_len = (int64_t)H.ent.size();
   (void)nnz;
   return true;
 }
@@ -953,37 +925,10 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   // The (or,and) semiring on bits, when asked for (or_and_bits: 1 = beside the ordinary plan, 2 = instead of it: a BFS
   // harness never launches another semiring on its matrix)
   size_t *acct = &m->bits_bytes;
-  if (opt.or_and_bits > 0 && nnz > 0) {
-    BitsHost bh;
-    if (build_bits_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, bh)) {
-      m->n_bits_items = (int32_t)bh.items.size();
-      m->bits_ct = bh.n_ct;
-      m->bits_entries = bh.entries;
-      m->bits_only = opt.or_and_bits >= 2;
-      DEV_ARRAY(m->d_bits_items, bh.items.data(), bh.items.size() * sizeof(BitsItem), 32);
-      DEV_ARRAY(m->d_bits_ent, bh.ent.data(), bh.ent.size() * 4, 16);
-      DEV_ARRAY(m->d_bits_sub, bh.bsub.data(), bh.bsub.size() * 4, 16);
-      DEV_ARRAY(m->d_bits_rr0, bh.rr_item0.data(), bh.rr_item0.size() * 4, 0);
-      DEV_ARRAY(m->d_xbits, (const uint64_t *)nullptr, (size_t)bh.n_ct * (BITS_BC / 8), 0);
-      DEV_ARRAY(m->d_bits_partial, (const uint32_t *)nullptr, (size_t)std::max<size_t>(bh.items.size(), 1) * (BITS_BR / 8), 0);
-      HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
-    }
-  }
-  if (m->bits_only && m->d_bits_items) {
-    m->plan = PLAN_STREAM;
-    *out = m;
-    return SH_OK;
-  }
-  m->bits_only = false;
-  // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
-  // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
-  TiledHost th;
-  TiledDevArrays td;   // the big arrays when the layout was built on the device
-  struct TdGuard { TiledDevArrays &t; ~TdGuard() { t.release(); } } td_guard{td};   // (whatever was not adopted below)
-  lap(nullptr);
   const int64_t padded = ((nnz + 3) & ~int64_t(3)) + 4;   // the tail is padded so that 16-byte loads at the end stay in bounds
   bool csr_on_device = false;
   auto upload_csr_arrays = [&]() -> int {   // row_ptr / col_idx / val as they are: plan A's arrays, and the device builder's input
+    size_t *const acct_before = acct;
     acct = &m->stream_bytes;
     DEV_ARRAY(m->d_row_ptr, row_ptr, (rows + 1) * 4, 0);
     DEV_ARRAY(m->d_col, (const int32_t *)nullptr, padded * 4, 0);
@@ -995,14 +940,66 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       HIP_TRY_M(hipMemcpyAsync(m->d_val, val, nnz * 4, hipMemcpyHostToDevice, e->stream));
     }
     csr_on_device = true;
+    acct = acct_before;
     return SH_OK;
   };
+  const bool device_build = opt.build == 2 || (opt.build == 0 && nnz >= DEVICE_BUILD_MIN_NNZ);
+  auto drop_csr_arrays = [&]() {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(m->d_row_ptr); (void)hipFree(m->d_col); (void)hipFree(m->d_val);
+    m->d_row_ptr = nullptr; m->d_col = nullptr; m->d_val = nullptr;
+    m->stream_bytes = 0;
+    csr_on_device = false;
+  };
+  if (opt.or_and_bits > 0 && nnz > 0) {
+    BitsHost bh;
+    int built = -1;   // 1 built, 0 the layout does not apply, -1 not tried / a device step failed: the host builder
+    uint32_t *dev_ent = nullptr;
+    if (device_build) {
+      if (const int rc = upload_csr_arrays()) return rc;
+      std::string why;
+      built = build_bits_plan_gpu(e->stream, rows, cols, nnz, m->d_row_ptr, m->d_col, m->d_val, bh, &dev_ent, why);
+      if (built != 1) { m->build_note = why; bh = BitsHost(); }
+    }
+    if (built < 0) built = build_bits_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, bh) ? 1 : 0;
+    if (built == 1) {
+      acct = &m->bits_bytes;
+      m->n_bits_items = (int32_t)bh.items.size();
+      m->bits_ct = bh.n_ct;
+      m->bits_entries = bh.entries;
+      m->bits_only = opt.or_and_bits >= 2;
+      if (dev_ent) { m->d_bits_ent = dev_ent; *acct += (size_t)bh.ent_len * 4 + SLACK_WIDE; m->built_on_device = true; }
+      else DEV_ARRAY(m->d_bits_ent, bh.ent.data(), bh.ent.size() * 4, SLACK_WIDE);
+      DEV_ARRAY(m->d_bits_items, bh.items.data(), bh.items.size() * sizeof(BitsItem), 32);
+      DEV_ARRAY(m->d_bits_sub, bh.bsub.data(), bh.bsub.size() * 4, 16);
+      DEV_ARRAY(m->d_bits_rr0, bh.rr_item0.data(), bh.rr_item0.size() * 4, 0);
+      DEV_ARRAY(m->d_xbits, (const uint64_t *)nullptr, (size_t)bh.n_ct * (BITS_BC / 8), 0);
+      DEV_ARRAY(m->d_bits_partial, (const uint32_t *)nullptr, (size_t)std::max<size_t>(bh.items.size(), 1) * (BITS_BR / 8), 0);
+      HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
+    }
+  }
+  if (m->bits_only && m->d_bits_items) {
+    if (csr_on_device) drop_csr_arrays();
+    m->plan = PLAN_STREAM;
+    *out = m;
+    return SH_OK;
+  }
+  m->bits_only = false;
+  // The tiled plan first: when it is chosen and nothing asks for a timing of both plans, the CSR arrays
+  // (8 B per entry) are neither uploaded nor kept -- the tiled kernels read their own layout only.
+  TiledHost th;
+  TiledDevArrays td;   // the big arrays when the layout was built on the device
+  struct TdGuard { TiledDevArrays &t; ~TdGuard() { t.release(); } } td_guard{td};   // (whatever was not adopted below)
+  lap(nullptr);
   // Where the tiled layout is built (sh_plan_options::build): on the device from the CSR arrays (plan_gpu.hip; the
   // default), or by the host builder below -- also the fallback when a device step fails.  Same bytes either way.
   bool want_tiled = choose_plan(opt, cols, nnz) == PLAN_TILED && nnz > 0;
   bool tiled = false;
-  if (want_tiled && (opt.build == 2 || (opt.build == 0 && nnz >= DEVICE_BUILD_MIN_NNZ))) {
-    if (const int rc = upload_csr_arrays()) return rc;
+  const bool bits_on_device = m->built_on_device;
+  m->built_on_device = false;   // (from here on: the tiled layout)
+  if (want_tiled && device_build) {
+    if (!csr_on_device)
+      if (const int rc = upload_csr_arrays()) return rc;
     lap("H2D of the CSR arrays");
     std::string why;
     const int g = build_tiled_plan_gpu(e->stream, rows, cols, nnz, row_ptr, m->d_row_ptr, m->d_col, m->d_val, opt, e->n_cus, th, td, why);
@@ -1045,10 +1042,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     }
     HIP_TRY_M(hipStreamSynchronize(e->stream)); // host vectors die at the end of this block
   } else if (csr_on_device) {
-    HIP_TRY_M(hipStreamSynchronize(e->stream));
-    (void)hipFree(m->d_row_ptr); (void)hipFree(m->d_col); (void)hipFree(m->d_val);
-    m->d_row_ptr = nullptr; m->d_col = nullptr; m->d_val = nullptr;
-    m->stream_bytes = 0;
+    drop_csr_arrays();
   }
   acct = &m->tiled_bytes;
   if (tiled) {
@@ -1101,6 +1095,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
 #undef HIP_TRY_M
   if (tune)
     autotune_plan(e, m);   // frees the arrays of the plan that lost
+  if (bits_on_device && !tiled) m->built_on_device = true;   // (a matrix whose only device-built layout is the bit-blocked one)
   *out = m;
   return SH_OK;
 }
@@ -1876,6 +1871,53 @@ extern "C" int sh_debug_compare_builds(sh_engine *e, int64_t rows, int64_t cols,
   if (!hip_ok) { rep += "hipMemcpy (download) failed\n"; return finish(-3); }
   return finish(diffs);
 }
+// The bit-blocked (or,and) layout built by both builders and compared: 0 = identical, else the number of differing
+// arrays; -1 host refused, -2 device refused / failed, -3 HIP error here.
+extern "C" int sh_debug_compare_bits_builds(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr,
+                                            const int32_t *col_idx, const void *val, char *report, int64_t cap) {
+  std::string rep;
+  auto finish = [&](int rc) { if (report && cap > 0) snprintf(report, (size_t)cap, "%s", rep.c_str()); return rc; };
+  if (!e || nnz <= 0) { rep = "bad argument"; return finish(-3); }
+  if (hipSetDevice(e->device) != hipSuccess) { rep = "hipSetDevice"; return finish(-3); }
+  sh_plan_options opt;
+  sh_plan_options_default(&opt);
+  BitsHost hh, hg;
+  if (!build_bits_plan(rows, cols, nnz, row_ptr, col_idx, (const uint32_t *)val, opt, hh)) { rep = "host builder refused"; return finish(-1); }
+  struct Guard { std::vector<void *> p; ~Guard() { for (void *q : p) (void)hipFree(q); } } guard;
+  int32_t *d_rp = nullptr, *d_ci = nullptr;
+  uint32_t *d_val = nullptr, *d_ent = nullptr;
+  if (hipMalloc((void **)&d_rp, (size_t)(rows + 1) * 4) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_rp);
+  if (hipMalloc((void **)&d_ci, (size_t)nnz * 4 + 32) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_ci);
+  if (hipMalloc((void **)&d_val, (size_t)nnz * 4 + 32) != hipSuccess) { rep = "hipMalloc"; return finish(-3); }
+  guard.p.push_back(d_val);
+  if (hipMemcpy(d_rp, row_ptr, (size_t)(rows + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_ci, col_idx, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_val, val, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess) { rep = "hipMemcpy"; return finish(-3); }
+  std::string why;
+  if (build_bits_plan_gpu(e->stream, rows, cols, nnz, d_rp, d_ci, d_val, hg, &d_ent, why) != 1) { rep = "device builder: " + why; return finish(-2); }
+  guard.p.push_back(d_ent);
+  int diffs = 0;
+  char line[256];
+  auto same = [&](const char *name, const void *a, size_t na, const void *b, size_t nb) {
+    if (na != nb || (na && memcmp(a, b, na) != 0)) {
+      size_t k = 0;
+      while (k < std::min(na, nb) && ((const uint8_t *)a)[k] == ((const uint8_t *)b)[k]) k++;
+      snprintf(line, sizeof line, "%s: %zu vs %zu bytes, first difference at byte %zu\n", name, na, nb, k);
+      rep += line; diffs++;
+    }
+  };
+  std::vector<uint32_t> ent((size_t)hg.ent_len);
+  if (hipMemcpy(ent.data(), d_ent, ent.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { rep = "hipMemcpy (download)"; return finish(-3); }
+  same("ent", hh.ent.data(), hh.ent.size() * 4, ent.data(), ent.size() * 4);
+  same("items", hh.items.data(), hh.items.size() * sizeof(BitsItem), hg.items.data(), hg.items.size() * sizeof(BitsItem));
+  same("bsub", hh.bsub.data(), hh.bsub.size() * 4, hg.bsub.data(), hg.bsub.size() * 4);
+  same("rr_item0", hh.rr_item0.data(), hh.rr_item0.size() * 4, hg.rr_item0.data(), hg.rr_item0.size() * 4);
+  if (hh.entries != hg.entries || hh.n_rr != hg.n_rr || hh.n_ct != hg.n_ct || hh.ent_len != hg.ent_len) { rep += "scalars differ\n"; diffs++; }
+  return finish(diffs);
+}
+
 // Placement experiments (tools/placement_probe.py): move one array of the tiled plan to a fresh allocation (hold != 0:
 // the old one is kept allocated -- and leaked until process exit -- so that the new one cannot land in the same place),
 // return its new address.  which: 0 P, 1 tcol, 2 tcode / tval, 3 pslot, 4 gblk, 5 ptab, 6 obase, 7 lrp.

@@ -5,6 +5,7 @@
 #pragma once
 #include "../../include/sparseharness_hip.h"
 #include "kernels.hip.h"
+#include "bits.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -265,5 +266,51 @@ constexpr size_t SLACK_TCODE = 64, SLACK_WIDE = 16;
 int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *h_rp, const int32_t *d_rp,
                           const int32_t *d_ci, const uint32_t *d_val, const sh_plan_options &opt, int n_cus, TiledHost &H,
                           TiledDevArrays &D, std::string &why);
+
+// ---- the (or,and) semiring on bits (see bits.hip.h) -----------------------
+struct BitsHost {
+  std::vector<BitsItem> items;
+  std::vector<uint32_t> ent;     // (empty when the device builder left the entries on the device)
+  std::vector<int32_t> bsub, rr_item0;
+  int32_t n_rr = 0, n_ct = 0;
+  int64_t entries = 0;   // entries with a non-zero value and a column in range
+  int64_t ent_len = 0;   // words of the entry array (padding and the 8 trailing words included)
+};
+// From the live entries per cell (cell = (row range, column block, sub-range), cnt[ncell + 1]): where every cell's
+// entries start (each padded to a multiple of 8), and the work items: blocks with more than 2^20 entries are cut at
+// sub-range boundaries.  false: the entry array would exceed int32 indexing.
+static inline bool bits_starts_and_items(BitsHost &H, const std::vector<int64_t> &cnt, std::vector<int64_t> &start) {
+  const int64_t ncell = (int64_t)H.n_rr * H.n_ct * BITS_NSUB;
+  int64_t pos = 0;
+  H.entries = 0;
+  for (int64_t k = 0; k < ncell; k++) { start[(size_t)k] = pos; pos += (cnt[(size_t)k] + 7) & ~int64_t(7); H.entries += cnt[(size_t)k]; }
+  start[(size_t)ncell] = pos;
+  if (pos > INT32_MAX - 8) return false;
+  const int64_t max_item = 1 << 20;
+  H.rr_item0.assign((size_t)H.n_rr + 1, 0);
+  for (int32_t rr = 0; rr < H.n_rr; rr++) {
+    H.rr_item0[(size_t)rr] = (int32_t)H.items.size();
+    for (int32_t ct = 0; ct < H.n_ct; ct++) {
+      const int64_t c0 = ((int64_t)rr * H.n_ct + ct) * BITS_NSUB;
+      if (start[(size_t)(c0 + BITS_NSUB)] == start[(size_t)c0]) continue;   // an empty block
+      for (int sub0 = 0; sub0 < BITS_NSUB;) {
+        int sub1 = sub0 + 1;
+        while (sub1 < BITS_NSUB && start[(size_t)(c0 + sub1 + 1)] - start[(size_t)(c0 + sub0)] <= max_item) sub1++;
+        if (start[(size_t)(c0 + sub1)] > start[(size_t)(c0 + sub0)]) {
+          BitsItem it{rr, ct, (int32_t)start[(size_t)(c0 + sub0)], (int32_t)start[(size_t)(c0 + sub1)], sub0, sub1, (int32_t)H.bsub.size(), 0};
+          for (int k = sub0; k <= sub1; k++) H.bsub.push_back((int32_t)start[(size_t)(c0 + k)]);
+          H.items.push_back(it);
+        }
+        sub0 = sub1;
+      }
+    }
+  }
+  H.rr_item0[(size_t)H.n_rr] = (int32_t)H.items.size();
+  return true;
+}
+// The entry array of the bit-blocked layout built on the device (plan_gpu.hip): 1 built (*d_ent holds H.ent_len words
+// + SLACK_WIDE bytes, H the items), 0 not applicable (as the host builder), -1 a device step failed.
+int build_bits_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *d_rp, const int32_t *d_ci,
+                        const uint32_t *d_val, BitsHost &H, uint32_t **d_ent, std::string &why);
 
 } // namespace sh

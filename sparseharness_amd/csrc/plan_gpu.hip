@@ -454,6 +454,45 @@ __global__ void k_distinct(const uint32_t *__restrict__ val, int64_t n, unsigned
   }
 }
 
+// ---- the bit-blocked (or,and) layout
+// key = the entry's cell ((row range, column block, sub-range), as the host's cell_of), dead entries (zero value or column
+// out of range) = ncell: they sort behind all live ones
+__global__ void k_bits_keys(const uint32_t *__restrict__ row_of, const int32_t *__restrict__ ci, const uint32_t *__restrict__ val, int64_t n,
+                            int64_t cols, int32_t n_ct, uint32_t ncell, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+  const int64_t j = GID;
+  if (j >= n) return;
+  const int32_t c = ci[j];
+  const uint32_t r = row_of[j];
+  const bool live = val[j] != 0u && (uint32_t)c < (uint32_t)cols;
+  key[j] = live ? (uint32_t)((((int64_t)(r / BITS_BR) * n_ct + c / BITS_BC) * BITS_NSUB) + (r % BITS_BR) / BITS_SUB) : ncell;
+  idx[j] = (uint32_t)j;
+}
+__global__ void k_bits_bounds(const uint32_t *__restrict__ key, int64_t n, uint32_t ncell, uint32_t *__restrict__ cstart, uint32_t *__restrict__ cend) {
+  const int64_t i = GID;
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  if (k >= ncell) return;
+  if (i == 0 || key[i - 1] != k) cstart[k] = (uint32_t)i;
+  if (i == n - 1 || key[i + 1] != k) cend[k] = (uint32_t)i + 1u;
+}
+// entry word = column inside the block | row inside the sub-range << 19; a cell's last entry also writes the padding
+__global__ void k_bits_fill(const uint32_t *__restrict__ key, const uint32_t *__restrict__ jS, const uint32_t *__restrict__ row_of,
+                            const int32_t *__restrict__ ci, int64_t n, uint32_t ncell, const uint32_t *__restrict__ cstart,
+                            const uint32_t *__restrict__ cend, const uint32_t *__restrict__ start, uint32_t *__restrict__ ent) {
+  const int64_t i = GID;
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  if (k >= ncell) return;
+  const uint32_t j = jS[i];
+  const uint32_t w = (uint32_t)(ci[j] % BITS_BC) | ((row_of[j] % BITS_SUB) << 19);
+  const uint32_t pos = start[k] + ((uint32_t)i - cstart[k]);
+  ent[pos] = w;
+  if ((uint32_t)i + 1u == cend[k]) {
+    const uint32_t cnt = cend[k] - cstart[k], end = start[k] + ((cnt + 7u) & ~7u);
+    for (uint32_t q = pos + 1; q < end; q++) ent[q] = w;
+  }
+}
+
 } // namespace
 
 // One scratch buffer for all rocPRIM calls, grown on demand.
@@ -898,6 +937,82 @@ hip_failed:
   return -1;
 #undef GT
 #undef PHASE
+#undef POOL_OK
+#undef LAUNCH
+#undef CUB
+}
+
+int build_bits_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *d_rp, const int32_t *d_ci,
+                        const uint32_t *d_val, BitsHost &H, uint32_t **d_ent, std::string &why) {
+  H.n_rr = (int32_t)std::max<int64_t>(1, (rows + BITS_BR - 1) / BITS_BR);
+  H.n_ct = (int32_t)std::max<int64_t>(1, (cols + BITS_BC - 1) / BITS_BC);
+  const int64_t ncell = (int64_t)H.n_rr * H.n_ct * BITS_NSUB, n = nnz;
+  if (ncell > (int64_t)1 << 27 || nnz <= 0 || rows <= 0) { why = "not applicable"; return 0; }
+  DevPool pool;
+  pool.stream = stream;
+  CubTemp tmp;
+  hipError_t herr = hipSuccess;
+  const char *hwhat = "";
+#define GT(call)                                                                                     \
+  do {                                                                                               \
+    herr = (call);                                                                                   \
+    if (herr != hipSuccess) { hwhat = #call; goto hip_failed; }                                      \
+  } while (0)
+#define POOL_OK()                                                                                    \
+  do {                                                                                               \
+    if (pool.err != hipSuccess) { herr = pool.err; hwhat = "hipMalloc (temporaries)"; goto hip_failed; } \
+  } while (0)
+#define LAUNCH(kernel, count, ...)                                                                   \
+  do {                                                                                               \
+    if ((count) > 0) hipLaunchKernelGGL(kernel, grid_for(count), dim3(PBS), 0, stream, __VA_ARGS__);  \
+  } while (0)
+#define CUB(...)                                                                                     \
+  do {                                                                                               \
+    size_t _b = 0;                                                                                   \
+    void *_t = nullptr;                                                                              \
+    { auto _call = [&](void *d_temp_storage, size_t &temp_storage_bytes) { return __VA_ARGS__; };    \
+      GT(_call(_t, _b));                                                                             \
+      GT(tmp.reserve(_b));                                                                           \
+      _t = tmp.p;                                                                                    \
+      GT(_call(_t, _b)); }                                                                           \
+  } while (0)
+  uint32_t *head = nullptr, *row_of = nullptr, *key_in = nullptr, *idx_in = nullptr, *key = nullptr, *jS = nullptr, *cstart = nullptr,
+           *cend = nullptr, *d_start = nullptr;
+  std::vector<uint32_t> hs((size_t)ncell), he((size_t)ncell), st32((size_t)ncell + 1);
+  std::vector<int64_t> cnt((size_t)ncell + 1, 0), start((size_t)ncell + 1, 0);
+  head = pool.get<uint32_t>((size_t)n, true); row_of = pool.get<uint32_t>((size_t)n);
+  key_in = pool.get<uint32_t>((size_t)n); idx_in = pool.get<uint32_t>((size_t)n);
+  key = pool.get<uint32_t>((size_t)n); jS = pool.get<uint32_t>((size_t)n);
+  cstart = pool.get<uint32_t>((size_t)ncell + 1, true); cend = pool.get<uint32_t>((size_t)ncell + 1, true);
+  d_start = pool.get<uint32_t>((size_t)ncell + 1);
+  POOL_OK();
+  LAUNCH(k_row_heads, rows, d_rp, rows, head);
+  CUB(hipcub::DeviceScan::InclusiveScan(d_temp_storage, temp_storage_bytes, head, row_of, hipcub::Max(), n, stream));
+  LAUNCH(k_bits_keys, n, row_of, d_ci, d_val, n, cols, H.n_ct, (uint32_t)ncell, key_in, idx_in);
+  // stable: inside a cell the entries keep the order of the CSR walk (rows ascending), so the sub-range of an entry
+  // follows from its position
+  CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, key_in, key, idx_in, jS, n, 0, bits_for((uint64_t)ncell), stream));
+  LAUNCH(k_bits_bounds, n, key, n, (uint32_t)ncell, cstart, cend);
+  GT(hipMemcpyAsync(hs.data(), cstart, (size_t)ncell * 4, hipMemcpyDeviceToHost, stream));
+  GT(hipMemcpyAsync(he.data(), cend, (size_t)ncell * 4, hipMemcpyDeviceToHost, stream));
+  GT(hipStreamSynchronize(stream));
+  for (int64_t k = 0; k < ncell; k++) cnt[(size_t)k] = (int64_t)he[(size_t)k] - (int64_t)hs[(size_t)k];
+  if (!bits_starts_and_items(H, cnt, start)) { why = "entry array exceeds int32 indexing"; return 0; }
+  for (int64_t k = 0; k <= ncell; k++) st32[(size_t)k] = (uint32_t)start[(size_t)k];
+  H.ent_len = start[(size_t)ncell] + 8;
+  GT(hipMemcpyAsync(d_start, st32.data(), ((size_t)ncell + 1) * 4, hipMemcpyHostToDevice, stream));
+  GT(hipMalloc((void **)d_ent, (size_t)H.ent_len * 4 + SLACK_WIDE));
+  GT(hipMemsetAsync(*d_ent, 0, (size_t)H.ent_len * 4, stream));
+  LAUNCH(k_bits_fill, n, key, jS, row_of, d_ci, n, (uint32_t)ncell, cstart, cend, d_start, *d_ent);
+  GT(hipStreamSynchronize(stream));
+  GT(hipGetLastError());
+  return 1;
+hip_failed:
+  why = std::string(hwhat) + ": " + hipGetErrorString(herr);
+  (void)hipGetLastError();
+  if (*d_ent) { (void)hipFree(*d_ent); *d_ent = nullptr; }
+  return -1;
+#undef GT
 #undef POOL_OK
 #undef LAUNCH
 #undef CUB

@@ -36,6 +36,8 @@ def tools():
     lib.sh_engine_destroy.argtypes = [C.c_void_p]
     lib.sh_debug_compare_builds.restype = C.c_int
     lib.sh_debug_compare_builds.argtypes = [C.c_void_p] + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.POINTER(abi.sh_plan_options), C.c_char_p, C.c_int64]
+    lib.sh_debug_compare_bits_builds.restype = C.c_int
+    lib.sh_debug_compare_bits_builds.argtypes = [C.c_void_p] + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_char_p, C.c_int64]
     e = C.c_void_p()
     assert lib.sh_engine_create(0, C.byref(e)) == 0
     yield lib, e
@@ -113,6 +115,21 @@ def test_device_builder_equals_host_builder_rmat(tools):
     rp, ci, va = H.rmat(18, seed=5)
     rc, report = compare(tools, 1 << 18, 1 << 18, rp, ci, va)
     assert rc == 0, (rc, report)
+
+
+def test_device_bits_builder_equals_host_builder(tools):
+    """The bit-blocked (or,and) layout: entries, work items and sub-range offsets of both builders are the same bytes."""
+    lib, e = tools
+    rng = np.random.default_rng(77)
+    cases = [random_matrix(rng, 3000, 100_000, 12, 3, values="few") + (3000, 100_000),
+             random_matrix(rng, 600_000, 1_500_000, 6, 2, oob=True, values="few") + (600_000, 1_500_000)]
+    rp, ci, va = H.rmat(18, seed=5)
+    cases.append((rp, ci, va, 1 << 18, 1 << 18))
+    for rp, ci, va, rows, cols in cases:
+        rp, ci, vi = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(va).astype(np.int32)
+        buf = C.create_string_buffer(2048)
+        rc = lib.sh_debug_compare_bits_builds(e, rows, cols, len(ci), _p(rp), _p(ci), _p(vi), buf, len(buf))
+        assert rc == 0, (rows, cols, rc, buf.value.decode())
 
 
 def test_device_builder_through_the_abi():

@@ -168,6 +168,9 @@ static inline void cut_work_items(const int CT, const std::vector<int64_t> &run_
     return n;
   };
   // Round 3 (pair folding, same box): 48 K 0.453, 64 K 0.443, 96 K 0.448, 128 K 0.437 ms at full size -> 128 K under the same rule.
+  // (Six rounds per size, every round a fresh process = fresh allocations: 96 K 0.4455, 128 K 0.4360, 160 K 0.4330, 192 K 0.4324,
+  // 256 K 0.4349 ms; odd multiples of 1024 entries -- no power-of-two stride between the workgroups' streams -- change nothing:
+  // profiles/r03_ab_chunk_sizes_*.log.  Within the +-1 % that the placement of the arrays alone moves the time.)
   const int64_t enough = 6ll * std::max(n_cus, 1);
   int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(131072) >= enough ? 131072 : (items_at(65536) >= enough ? 65536 : 49152));
   chunk = std::max<int64_t>(1024, chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips

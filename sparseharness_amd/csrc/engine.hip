@@ -279,7 +279,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
                              const int32_t *ci, const uint32_t *val, const sh_plan_options &opt, int n_cus, TiledHost &H) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   if (CT > 65535) return false;   // (tile numbers travel as 16-bit values in the builder; 2.1 G columns: shard the matrix)
-  const bool fold = opt.fold != 0;
+  const bool fold = opt.fold != 0 && TCOL_FOLD != 0;
   lap(nullptr);
   // A row is "heavy" when it averages >= 8 entries per column tile (or cannot fit a bin): its
   // (row, tile) runs are summed inside phase 1 instead of travelling through P.
@@ -1053,7 +1053,7 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     m->stream_len = th.stream_len;
     m->p_len = th.p_len;
     m->light_entries = th.light_entries;
-    m->fold = opt.fold != 0;
+    m->fold = opt.fold != 0 && TCOL_FOLD != 0;
     m->bin_r0.reserve(th.bins.size());
     for (const RowBin &b : th.bins) m->bin_r0.push_back(b.r0);
     DEV_ARRAY(m->d_bins, th.bins.data(), th.bins.size() * sizeof(RowBin), 0);
@@ -1662,8 +1662,8 @@ int emulate(const TiledHost &H, int64_t rows, int64_t cols, const uint32_t *x, u
           const bool takes = (lane & 1) == 0 && lane + 1 < 64 && flagged(g + 1);
           if (pos + 4 > H.p_len) return -11;
           for (int k = 0; k < 4; k++) {
-            T acc = prod(g * 4 + k, k == 0 ? 0x7FFFu : 0xFFFFu);
-            if (takes) acc = SR::add(acc, prod((g + 1) * 4 + k, k == 0 ? 0x7FFFu : 0xFFFFu));
+            T acc = prod(g * 4 + k, k == 0 ? TCOL_MASK : 0xFFFFu);
+            if (takes) acc = SR::add(acc, prod((g + 1) * 4 + k, k == 0 ? TCOL_MASK : 0xFFFFu));
             P[(size_t)pos + k] = tobits<T>(acc);
           }
           pos += 4;
@@ -1946,6 +1946,13 @@ extern "C" int sh_debug_move_array(sh_engine *e, sh_csr *m, int which, int hold,
   if (!hold) (void)hipFree(*slot);
   *slot = fresh;
   if (address) *address = (uint64_t)(uintptr_t)fresh;
+  return SH_OK;
+}
+// (placement experiments) point the matrix at another product array allocated by sh_debug_move_array(which = 0, hold = 1)
+extern "C" int sh_debug_set_P(sh_engine *e, sh_csr *m, uint64_t address) {
+  if (!e || !m || m->plan != PLAN_TILED || !address) return SH_EINVAL;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return SH_EHIP;
+  m->d_P = (uint32_t *)(uintptr_t)address;
   return SH_OK;
 }
 #endif

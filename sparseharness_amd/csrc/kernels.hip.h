@@ -501,9 +501,12 @@ constexpr int TBIN_ROWS = TBIN / 8;     // rows per bin (row_ptr slice in LDS)
 constexpr int TCHUNK = SH_TCHUNK;       // entries per phase-1 workgroup
 constexpr int P1U = SH_P1_UNROLL;       // 16-byte groups in flight per thread in phase 1
 constexpr uint16_t TCOL_IDENTITY = (uint16_t)TCOLS; // col16 code of "x reads as the identity": the LDS slot behind the tile holds it
-constexpr uint16_t TCOL_FOLD = 0x8000;     // on the FIRST column code of a light group: the group's 4 products are folded into those of the group (lane) in front
+// TCOL_FOLD: on the FIRST column code of a light group: the group's 4 products are folded into those of the group (lane) in
+// front.  (Experimental builds with tiles wider than 15 bits have no room for the flag: they do not fold.)
+constexpr uint16_t TCOL_FOLD = SH_TCOLS < 32768 ? 0x8000 : 0;
+constexpr uint32_t TCOL_MASK = SH_TCOLS < 32768 ? 0x7FFFu : 0xFFFFu;
 constexpr uint16_t TSLOT_PAD = 0xFFFF;     // slot16 marker: padding product
-static_assert(TCOLS % 8 == 0 && TCOLS < 32768 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile; bit 15 is the fold flag");
+static_assert(TCOLS % 8 == 0 && TCOLS <= 65528 && TCOL_IDENTITY == TCOLS, "the identity column code indexes the slot behind the x tile; bit 15 is the fold flag when the tile leaves it free");
 // Heavy rows: every (row, tile) piece is padded to whole STRIPS of HSTRIP consecutive stream entries.  One
 // lane of phase 1 sums a strip (wide loads, 16 products in stream order); consecutive lanes whose strips
 // belong to the same piece are then combined by a segmented wave scan in DPP, and the last lane of each run
@@ -625,7 +628,7 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     else
       v = w;
     // (bit 15 of a group's first column code is the fold flag)
-    pr[0] = SR::mul(from_bits<T>(xs[c.x & 0x7FFFu]), from_bits<T>(v.x));
+    pr[0] = SR::mul(from_bits<T>(xs[c.x & TCOL_MASK]), from_bits<T>(v.x));
     pr[1] = SR::mul(from_bits<T>(xs[c.x >> 16]), from_bits<T>(v.y));
     pr[2] = SR::mul(from_bits<T>(xs[c.y & 0xFFFFu]), from_bits<T>(v.z));
     pr[3] = SR::mul(from_bits<T>(xs[c.y >> 16]), from_bits<T>(v.w));
@@ -673,7 +676,7 @@ __device__ __forceinline__ void tiled_phase1_chunk(
           const bool valid = g < le;
           T pr[4];
           products(vw[k], c[k], pr);
-          const bool folds = valid && (c[k].x & 0x8000u) != 0;          // this lane is the B of a pair
+          const bool folds = valid && (c[k].x & TCOL_FOLD) != 0;          // this lane is the B of a pair
           const uint64_t fm = __ballot(folds), sm = __ballot(valid && !folds);
           const bool takes = ((fm >> 1) >> lane) & 1u;                   // the lane behind folds into this one
 #pragma unroll

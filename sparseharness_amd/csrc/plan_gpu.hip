@@ -515,7 +515,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
                           TiledDevArrays &D, std::string &why) {
   const int CT = (int)std::max<int64_t>(1, (cols + TCOLS - 1) / TCOLS);
   if (CT > 65535 || nnz <= 0 || rows <= 0) { why = "not applicable"; return 0; }
-  const bool fold = opt.fold != 0;
+  const bool fold = opt.fold != 0 && TCOL_FOLD != 0;
   const int64_t per_tile = std::max(1, opt.heavy_per_tile);
   const int64_t heavy_thr = std::min<int64_t>(TBIN / 4, std::max<int64_t>(512, per_tile * CT));
   auto is_heavy = [&](int64_t r) { return (int64_t)h_rp[r + 1] - h_rp[r] >= heavy_thr; };

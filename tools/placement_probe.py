@@ -37,6 +37,28 @@ with Engine(0) as eng:
             for k, A in enumerate(mats):
                 times[k].append(median_ms(eng, A, xv, out))
         print(json.dumps({"builder": mats[0].builder()[0], "per_copy_ms": times}))
+    elif mode == "lottery":
+        # K candidate places for the product array P (all kept allocated), timed round-robin three times: is a candidate's
+        # time its own (then picking the best of K at upload is worth the spread), or does it drift with time?
+        lib = abi.load()
+        lib.sh_debug_move_array.restype = C.c_int
+        lib.sh_debug_move_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        lib.sh_debug_set_P.restype = C.c_int
+        lib.sh_debug_set_P.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        A = eng.upload_csr(n, n, rp, ci, va, build=2)
+        for _ in range(20):
+            median_ms(eng, A, xv, out)   # warm
+        cands = []
+        for k in range(K):
+            addr = C.c_uint64()
+            assert lib.sh_debug_move_array(eng.h, A.h, 0, 1, 0, C.byref(addr)) == 0
+            cands.append(addr.value)
+        times = [[] for _ in cands]
+        for rep in range(4):
+            for k, a in enumerate(cands):
+                assert lib.sh_debug_set_P(eng.h, A.h, a) == 0
+                times[k].append(median_ms(eng, A, xv, out, runs=15))
+        print(json.dumps({"candidates": [hex(a) for a in cands], "per_candidate_ms": times}))
     else:
         lib = abi.load()
         lib.sh_debug_move_array.restype = C.c_int

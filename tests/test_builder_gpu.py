@@ -27,8 +27,8 @@ def _p(a):
 @pytest.fixture(scope="module")
 def tools():
     """(library, engine handle) of the tools build: its own engine, since the comparison runs inside that library."""
-    if not os.path.exists(LIB):
-        subprocess.check_call(["make", "-s", "-C", CSRC, "emulate"])
+    rc = subprocess.call(["make", "-s", "-C", CSRC, "emulate"])   # (rebuilds only when a source is newer than the library)
+    assert rc == 0 or os.path.exists(LIB)
     lib = C.CDLL(LIB)
     lib.sh_plan_options_default.argtypes = [C.POINTER(abi.sh_plan_options)]
     lib.sh_engine_create.restype = C.c_int

@@ -75,12 +75,22 @@ static __global__ __launch_bounds__(BITS_TBS) void bits_blocks(const BitsItem *_
     uint4 t[NI];
 #pragma unroll
     for (int k = 0; k < NI; k++) t[k] = src[tid + k * BITS_TBS];
+    uint32_t nz = 0u;
 #pragma unroll
-    for (int k = 0; k < NI; k++) reinterpret_cast<uint4 *>(xs)[tid + k * BITS_TBS] = t[k];
+    for (int k = 0; k < NI; k++) {
+      reinterpret_cast<uint4 *>(xs)[tid + k * BITS_TBS] = t[k];
+      nz |= t[k].x | t[k].y | t[k].z | t[k].w;
+    }
     for (int i = tid; i < BITS_BR / 32; i += BITS_TBS) os[i] = 0u;
     if (tid <= it.sub1 - it.sub0) offs[tid] = bsub[it.soff + tid] >> 2;
+    // No x bit set in this column block (the first BFS iterations: a handful of frontier vertices): every product is
+    // 0, the item's partial bitmap is all zero and its entries need not be read at all.
+    if (!__syncthreads_or(nz != 0u)) {
+      uint4 *dst = reinterpret_cast<uint4 *>(partial + (size_t)blockIdx.x * (BITS_BR / 32));
+      for (int i = tid; i < BITS_BR / 32 / 4; i += BITS_TBS) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
   }
-  __syncthreads();
   // The item's entries are one 32-byte aligned stream (every sub-range is padded to a multiple of 8 entries by
   // repeating its last entry: OR does not mind).  A lane takes 8 CONSECUTIVE entries (two 16-byte loads): they are
   // ordered by row, so their hits fall into one or two 32-bit words of the result bitmap and are merged in registers

@@ -118,6 +118,22 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
   }
 }
 
+// The same with the y / previous-vector words of the row already in registers (requested before the row was summed:
+// the staged pass of the tiled plan's phase 2).
+template <class SR>
+__device__ inline void finish_row_loaded(int32_t row, typename SR::T dot, uint32_t y_bits, uint32_t prev_bits,
+                                         typename SR::T alpha, typename SR::T beta, bool use_y,
+                                         uint32_t *__restrict__ out, const StepDev &st) {
+  using T = typename SR::T;
+  const int64_t at = row_element(st, row);
+  T yv = use_y ? from_bits<T>(y_bits) : SR::identity();
+  T o = SR::epilogue(dot, alpha, yv, beta, use_y);
+  if (st.done) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else out[at] = to_bits<T>(o);
+  if (st.changed && SR::differs(from_bits<T>(prev_bits), o, st.delta))
+    *st.changed = 1;
+}
+
 // One workgroup reports "my rows of pieces [c0, c1) are written".  Called by ONE lane after every storing wave of
 // the workgroup has drained its (write-through) row stores and the workgroup has met at a barrier: one arrival per
 // piece; the arrival that completes a launch's round tells the host, which polls done_host[c].
@@ -1035,6 +1051,23 @@ __device__ __forceinline__ void tiled_phase2_run(
       }
       int32_t *cnt = sc.cnt + 4 * (j & 1);
       if (j >= 1) {
+        // the y / previous-vector words of the rows this lane finishes below are requested now, so that their latency
+        // runs under the reduction (R-MAT-23 (min,+) step: phase 2 +50..70 us against a launch without y when they were
+        // requested behind MID2; +20 us now: profiles/r03_epilogue_probe_{before,after}.json)
+        uint32_t yw[P2S_RPU], pw[P2S_RPU];
+        const bool same_words = use_y && st.changed != nullptr && st.prev + st.prev_off == y;
+        if (staged) {
+#pragma unroll
+          for (int k = 0; k < P2S_RPU; k++) {
+            const int i = rt + k * P2S_RD;
+            yw[k] = 0u; pw[k] = 0u;
+            if (i < prev.nr) {
+              const int64_t at = row_element(st, prev.r0 + i);
+              if (use_y) yw[k] = y[at];
+              if (st.changed != nullptr && !same_words) pw[k] = st.prev[st.prev_off + at];
+            }
+          }
+        }
         reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
                                                alpha, beta, use_y, out, st, staged ? dots : nullptr);   // contains MID
         if (staged) {
@@ -1044,7 +1077,8 @@ __device__ __forceinline__ void tiled_phase2_run(
           for (int k = 0; k < P2S_RPU; k++) {
             const int i = rt + k * P2S_RD;
             if (i < prev.nr && !(rpp[i] & RP_SKIP))
-              finish_row<SR>(prev.r0 + i, from_bits<typename SR::T>(dots[i]), y, alpha, beta, use_y, out, st);
+              finish_row_loaded<SR>(prev.r0 + i, from_bits<typename SR::T>(dots[i]), yw[k], same_words ? yw[k] : pw[k], alpha, beta,
+                                    use_y, out, st);
           }
         }
       } else {

@@ -7,6 +7,8 @@ bit-for-bit (the reference's own criterion, inc/harness.h:134); general float
 data within 1e-5 relative (north_star); BFS and SSSP vectors and iteration
 counts bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -747,13 +749,11 @@ def test_many_launches_with_changing_inputs_midsize(eng, plan):
     A.free()
 
 
-def _two_rank_worker(rank, world, port, sr, chunks, q):
-    import os
-
+def _two_rank_worker(rank, world, rendezvous, sr, chunks, q):
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (rendezvous through a file: a TCP port picked by the parent could be taken by someone else before rank 0 binds it)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
     try:
         from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
         rp, ci, va = H.rmat(15, seed=5)
@@ -778,7 +778,7 @@ def test_two_ranks_share_the_gpu_with_hip_local_step(sr, chunks, plan):
     convergence, every rank's final vector and launch count bit-identical to the single-process oracle loop."""
     if plan != "tiled":
         pytest.skip("once per run is enough (the engine picks the plan by size)")
-    import socket
+    import tempfile
 
     import torch.multiprocessing as mp
     rp, ci, va = H.rmat(15, seed=5)
@@ -787,18 +787,22 @@ def test_two_ranks_share_the_gpu_with_hip_local_step(sr, chunks, plan):
     a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
     x0 = O.initial_vector(sr, n)
     want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 60)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    rendezvous = os.path.join(tempfile.mkdtemp(prefix="sh_two_ranks_"), "store")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, sr, chunks, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, rendezvous, sr, chunks, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:   # (a worker that hangs must not outlive the test: it would hold the GPU and the run's pipes)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=30)
     assert res[1][4] > 0 and res[0][5] == res[1][4]          # rank 1 starts where rank 0 ends, past row 0
     for rank, final, iters, conv, _, _ in res:
         assert (iters, conv) == (w_it, w_conv), f"rank {rank}"

@@ -73,6 +73,14 @@ def test_plan_options_defaults_and_environment(monkeypatch):
     monkeypatch.setenv("SH_PLAN", "stream")
     lib.sh_plan_options_from_env(C.byref(o))
     assert (o.plan, o.value_coding) == (1, 8)
+    assert (o.build, o.or_and_bits) == (0, 0)            # where the layout is built: the engine decides by size
+    for text, want in (("host", 1), ("device", 2), ("gpu", 2), ("auto", 0)):
+        monkeypatch.setenv("SH_BUILD", text)
+        lib.sh_plan_options_from_env(C.byref(o))
+        assert o.build == want, text
+    monkeypatch.setenv("SH_OR_AND_BITS", "2")
+    lib.sh_plan_options_from_env(C.byref(o))
+    assert o.or_and_bits == 2
 
 
 def test_tiled_kernels_use_no_scratch_and_spill_nothing():

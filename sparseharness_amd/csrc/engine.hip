@@ -88,6 +88,7 @@ struct sh_csr {
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
   uint32_t round = 0;                         // reporting launches so far
   bool built_on_device = false;               // the tiled layout was built by plan_gpu.hip
+  bool skip_minplus = false;                  // every |value| < 2^103: FLT_MAX + |a| == FLT_MAX, so tiles of unreached x words may be skipped
   std::string build_note;                     // why the device builder was not used / fell back (empty: nothing to say)
 };
 enum { PLAN_STREAM = 0, PLAN_TILED = 1 };
@@ -698,6 +699,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   std::vector<int64_t> ob0((size_t)CT + 1, 0);
   for (int t = 0; t < CT; t++) ob0[(size_t)t + 1] = ob0[(size_t)t] + (((run_len[(size_t)t] + 255) & ~int64_t(255)) / 256);
   H.obase.assign((size_t)ob0[(size_t)CT] + 1, 0u);
+  H.obase[(size_t)ob0[(size_t)CT]] = (uint32_t)H.p_len;   // one entry behind the last block: obase[b + 1] - obase[b] = products of block b
   parallel_items(CT, 1, NT, [&](int64_t t, int) {
     int64_t pp = run_pstart[(size_t)t];
     const int64_t s0 = run_start[(size_t)t], s1 = s0 + run_len[(size_t)t];
@@ -1069,6 +1071,8 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
       m->n_vdict = (int)th.vdict.size();
       m->n_vdict_used = th.vdict_used;
       m->code_bits = th.code_bits;
+      m->skip_minplus = true;   // (known from the dictionary alone; raw values would need a pass over the matrix: not skipped)
+      for (int k = 0; k < th.vdict_used; k++) m->skip_minplus = m->skip_minplus && (th.vdict[(size_t)k] & 0x7FFFFFFFu) < 0x73000000u;   // |a| < 2^103
       td_n = td.n_tcode; PLAN_ARRAY(m->d_tcode, td.tcode, th.tcode, 1, SLACK_TCODE);
       DEV_ARRAY(m->d_vdict, th.vdict.data(), th.vdict.size() * 4, 0);
     } else {
@@ -1348,19 +1352,21 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
     {
       const TileChunk *ch = A->d_chunks;
       const dim3 grid((unsigned)A->n_chunks), block(TBS);
+      // tiles whose x words are all absorbing are not streamed (semiring.hip.h); (min,+) needs every |value| < 2^103
+      const int32_t skip_dead = SR::id == 1 ? (A->skip_minplus ? 1 : 0) : 1;
       if (A->n_chunks > 0) {
         if (A->n_vdict && A->code_bits == 4)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
         else if (A->n_vdict)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
         else
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
         HIP_TRY(e, hipGetLastError());
       }
     }

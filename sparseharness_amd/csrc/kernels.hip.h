@@ -594,9 +594,13 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     const TileChunk ch, uint32_t *xs, uint32_t *ds, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, Hook staged = NoHook()) {
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const bool skip_dead_tiles, Hook staged = NoHook()) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
+  // skip_dead_tiles (workgroup-uniform): when every x word of the tile is absorbing (SR::absorbing: an unreached vertex
+  // of SSSP, a vertex outside the BFS frontier) all products of the chunk are the identity and are written without
+  // reading the chunk's entries -- the first iterations of a search from one vertex touch a handful of tiles.
+  const bool may_skip = SR::has_absorbing && skip_dead_tiles;
   // the value words of one group of 4 entries: 4 values, 4 one-byte codes, or 4 nibbles
   using VWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint32_t, uint16_t>::type>::type;
   // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
@@ -613,7 +617,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   // first stream batch.  (LDS-DMA staging -- global_load_lds_dwordx4, no VGPR round trip -- was measured
   // neutral on the same box: 494-512 vs 494-497 us per SpMV.)  (Requesting it right behind the staging loads, so that its HBM latency runs
   // under the LDS writes, was measured SLOWER on the same box: 533 vs 508 us per SpMV.)
-  auto stage = [&](auto request_first) {
+  auto stage = [&](auto request_first) -> bool {
+    bool live_word = false;   // this thread staged a word that is not absorbing
     if (c0 + TCOLS <= cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
       // full tile, 16-byte aligned: 1 KiB per wave-instruction; every load is issued before the first
       // LDS write (a rolled loop would pay one memory latency per iteration)
@@ -623,16 +628,25 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       for (int k = 0; k < NI; k++)
         t[k] = reinterpret_cast<const uint4 *>(x + c0)[min(tid + k * TBS, TCOLS / 4 - 1)];
 #pragma unroll
-      for (int k = 0; k < NI; k++)
+      for (int k = 0; k < NI; k++) {
         if (tid + k * TBS < TCOLS / 4)
           reinterpret_cast<uint4 *>(xs)[tid + k * TBS] = t[k];
+        if (SR::has_absorbing)
+          live_word = live_word || !SR::absorbing(t[k].x) || !SR::absorbing(t[k].y) || !SR::absorbing(t[k].z) || !SR::absorbing(t[k].w);
+      }
     } else {
-      for (int i = tid; i < TCOLS; i += TBS)
-        xs[i] = (c0 + i < cols) ? x[c0 + i] : ident;
+      for (int i = tid; i < TCOLS; i += TBS) {
+        const uint32_t w = (c0 + i < cols) ? x[c0 + i] : ident;
+        xs[i] = w;
+        if (SR::has_absorbing) live_word = live_word || !SR::absorbing(w);
+      }
     }
-    __syncthreads();
+    bool live = true;
+    if (may_skip) live = __syncthreads_or(live_word ? 1 : 0) != 0;
+    else __syncthreads();
     staged();
-    request_first();
+    if (live) request_first();
+    return live;
   };
   // the four products of one 16-byte group: x gathered from LDS, values decoded when coded
   auto products = [&](const VWord &w, const uint2 &c, T (&pr)[4]) {
@@ -713,8 +727,16 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     uint2 ca[U], cb[U];
     uint32_t oa[U], obb[U];
     int g0 = gs + tid;
-    stage([&]() { load(g0, va, ca, oa); });
-    if (g0 - lane < le) {
+    const bool live = stage([&]() { load(g0, va, ca, oa); });
+    if (!live) {
+      // a dead tile: every block of 64 groups stores identity products where its own would have gone
+      // (obase[b + 1] - obase[b] products: the table carries one entry behind the last block)
+      const uint4 id4 = make_uint4(ident, ident, ident, ident);
+      for (int blk = tid >> 6; blk <= last_blk; blk += TBS / 64) {
+        const uint32_t p0 = obase[ch.ob0 + blk], p1 = obase[ch.ob0 + blk + 1];
+        if (p0 + 4u * (uint32_t)lane < p1) *reinterpret_cast<uint4 *>(P + p0 + 4u * lane) = id4;
+      }
+    } else if (g0 - lane < le) {
       for (;;) {
         load(g0 + S, vb, cb, obb);
         consume(g0, va, ca, oa);
@@ -778,8 +800,13 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     uint4 ca[2], cb[2];
     uint32_t da = 0, db = 0;
     int sid = s0 + tid;
-    stage([&]() { load(sid, va, ca, da); });
-    if (sid < s1) {
+    const bool live = stage([&]() { load(sid, va, ca, da); });
+    if (!live) {
+      for (int q = sid; q < s1; q += TBS) {   // a dead tile: identity partials, found through the strips' gdest words alone
+        const uint32_t d = gdest[q - sbase];
+        if (d & GD_LAST) partial[d & GD_SLOT_MASK] = ident;
+      }
+    } else if (sid < s1) {
       for (;;) {
         load(sid + TBS, vb, cb, db);
         consume(sid, va, ca, da);
@@ -800,7 +827,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate) {
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate, int32_t skip_dead_tiles) {
   __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC ? VDICT : 1];
   const TileChunk ch = chunks[blockIdx.x];
@@ -809,7 +836,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   SH_STAT(const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime(); __shared__ uint64_t st_staged;)
   SH_STAT(auto stamp = [&]() { if (threadIdx.x == 0) st_staged = __builtin_amdgcn_s_memrealtime(); };)
 #ifdef SH_STATS
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, stamp);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0, stamp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && g_p1_stats) {   // per chunk: kind, entries, start, staged, end (100 MHz ticks)
@@ -817,7 +844,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     S[0] = ch.hs <= ch.s; S[1] = (uint64_t)(ch.e - ch.s); S[2] = st_t0; S[3] = st_staged; S[4] = __builtin_amdgcn_s_memrealtime();
   }
 #else
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0);
 #endif
 }
 

@@ -918,7 +918,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     if (NB > 0) {
       LAUNCH(k_block_counts, NB * 64, D.tcol, d_ob0, d_run_start, d_run_len, CT, NB, bcnt);
       CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, bcnt, bscan, NB + 1, stream));
-      LAUNCH(k_scale4, NB, bscan, NB, D.obase);
+      LAUNCH(k_scale4, NB + 1, bscan, NB + 1, D.obase);   // (the entry behind the last block = all products: obase[b + 1] - obase[b] = products of block b)
       // every tile's products must end where the next tile's begin (the host builder's consistency check)
       GT(hipMemcpyAsync(&u32tmp, bscan + NB, 4, hipMemcpyDeviceToHost, stream));
       GT(hipStreamSynchronize(stream));

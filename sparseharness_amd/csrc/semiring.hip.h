@@ -14,6 +14,10 @@ struct PlusTimesF32 {
   using T = float;
   static constexpr int id = 0;
   __device__ static inline T identity() { return 0.0f; }
+  // absorbing(x): mul(x, a) == identity() for every a the matrix may hold -- a column tile of such x words contributes
+  // nothing and phase 1 of the tiled plan need not read its entries.  Not for (+,x): 0 * a is -0 for negative a.
+  static constexpr bool has_absorbing = false;
+  __device__ static inline bool absorbing(uint32_t) { return false; }
   __device__ static inline T mul(T x, T a) { return x * a; }   // mult(l,r) = l*r
   __device__ static inline T add(T acc, T p) { return acc + p; } // add(x,y) = x+y
   // doubleMultiplyAdd: (dpRes*alpha)+(rowIdxPair2*beta).  When beta == 0 the
@@ -33,6 +37,9 @@ struct MinPlusF32 {
   using T = float;
   static constexpr int id = 1;
   __device__ static inline T identity() { return 3.4028235E38f; }
+  // |x| == FLT_MAX: FLT_MAX + |a| rounds back to FLT_MAX while |a| < 2^103 (the engine checks the matrix' values)
+  static constexpr bool has_absorbing = true;
+  __device__ static inline bool absorbing(uint32_t xbits) { return (xbits & 0x7FFFFFFFu) == 0x7F7FFFFFu; }
   __device__ static inline T mul(T x, T a) { return fabsf(x) + fabsf(a); } // absadd
   __device__ static inline T add(T acc, T p) {                              // clmin
     return fabsf(acc) < fabsf(p) ? fabsf(acc) : fabsf(p);
@@ -52,6 +59,8 @@ struct OrAndI32 {
   using T = int32_t;
   static constexpr int id = 2;
   __device__ static inline T identity() { return 0; }
+  static constexpr bool has_absorbing = true;
+  __device__ static inline bool absorbing(uint32_t xbits) { return xbits == 0u; }
   __device__ static inline T mul(T x, T a) { return (x != 0) && (a != 0); } // bool_and
   __device__ static inline T add(T acc, T p) { return (acc != 0) || (p != 0); } // bool_or
   __device__ static inline T epilogue(T dot, T alpha, T y, T beta, bool use_y) { // doubleAndOr
@@ -70,6 +79,8 @@ struct MaxMinI32 {
   using T = int32_t;
   static constexpr int id = 3;
   __device__ static inline T identity() { return INT32_MIN; }
+  static constexpr bool has_absorbing = true;
+  __device__ static inline bool absorbing(uint32_t xbits) { return xbits == 0x80000000u; }
   __device__ static inline T mul(T x, T a) { return x < a ? x : a; }       // int_min
   __device__ static inline T add(T acc, T p) { return acc > p ? acc : p; } // int_max
   __device__ static inline T epilogue(T dot, T alpha, T y, T beta, bool use_y) { // doubleMinMax

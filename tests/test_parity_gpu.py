@@ -703,6 +703,59 @@ def test_folded_runs_match_oracle(eng, plan, sr):
     A.free()
 
 
+@pytest.mark.parametrize("sr", [O.MIN_PLUS_F32, O.OR_AND_I32, O.MAX_MIN_I32])
+@pytest.mark.parametrize("weights", ["coded", "raw", "huge"])
+def test_tiles_of_absorbing_x_are_skipped_exactly(eng, plan, sr, weights):
+    """Phase 1 of the tiled plan does not read the entries of a column tile whose x words are all absorbing (an
+    unreached vertex of SSSP: |x| = FLT_MAX; outside the BFS frontier: 0; INT_MIN for (max,min)) and writes identity
+    products instead.  x with no, one, a few and many live entries over 7 column tiles, heavy rows included, against
+    the oracle bit for bit; for (min,+) also with raw weights and with a weight of 2^110 in the dictionary
+    (FLT_MAX + 2^110 overflows: such a matrix is never skipped)."""
+    if plan != "tiled":
+        pytest.skip("belongs to the tiled plan")
+    if weights != "coded" and sr != O.MIN_PLUS_F32:
+        pytest.skip("the weight condition is (min,+)'s")
+    rng = np.random.default_rng(31)
+    rows, cols = 60_000, 7 * 32760 - 1000
+    deg = rng.poisson(9, rows).astype(np.int64)
+    deg[rng.integers(0, rows, 4)] = 3000          # heavy rows
+    deg[rng.integers(0, rows, 600)] = 150         # rows with several entries per tile: folded pairs
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, cols, nnz).astype(np.int32)
+    dt = O.elem_dtype(sr)
+    if weights == "raw":
+        vals = (rng.random(nnz) * 30).astype(np.float32)
+    else:
+        vals = rng.integers(1, 17, nnz).astype(dt)
+        if weights == "huge":
+            vals[rng.integers(0, nnz, 5)] = np.float32(2.0 ** 110)
+    if sr == O.MAX_MIN_I32:
+        vals = rng.integers(-50, 50, nnz).astype(dt)
+    A = eng.upload_csr(rows, cols, rp, ci, vals, plan=2)
+    assert A.plan()[0] == "tiled" and "tiles=7" in A.describe(), A.describe()
+    dead = {O.MIN_PLUS_F32: np.float32(np.finfo(np.float32).max), O.OR_AND_I32: 0, O.MAX_MIN_I32: O.INT_MIN}[sr]
+    a, b = {O.MIN_PLUS_F32: (0.0, 0.0), O.OR_AND_I32: (1, 0), O.MAX_MIN_I32: (700, -300)}[sr]
+    out = eng.alloc(rows).fill(0)
+    for live in (0, 1, 6, 2000, cols):
+        x = np.full(cols, dead, dt)
+        idx = rng.choice(cols, size=min(live, cols), replace=False)
+        x[idx] = (rng.integers(1, 9, len(idx)) if sr != O.MIN_PLUS_F32 else rng.random(len(idx)) * 9).astype(dt)
+        if sr == O.MIN_PLUS_F32 and live:
+            x[idx[0]] = -x[idx[0]]                 # absadd takes |x|: a negative finite x is live
+            if live > 1:
+                x[idx[1]] = -dead                  # ... and -FLT_MAX is as absorbing as FLT_MAX
+        y = np.full(rows, dead, dt)
+        xv, yv = eng.vector(x), eng.vector(y)
+        eng.spmv(sr, A, xv, yv, a, b, out)
+        np.testing.assert_array_equal(bits(out.download(dt)), bits(O.kernel(sr, rp, ci, vals, x, y, a, b)), err_msg=f"{live} live")
+        xv.free()
+        yv.free()
+    out.free()
+    A.free()
+
+
 def test_folded_runs_real_values_within_tolerance(eng, plan):
     """The same with real-valued weights and x: a fold changes the order of a row's float additions, so the
     yardstick is the north-star tolerance (1e-5 relative) against the exact (float64) dot."""

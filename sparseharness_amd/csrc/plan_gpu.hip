@@ -69,6 +69,10 @@ __global__ void k_iota(uint32_t *__restrict__ v, int64_t n) {
   const int64_t i = GID;
   if (i < n) v[i] = (uint32_t)i;
 }
+__global__ void k_iota64(uint64_t *__restrict__ v, int64_t n) {
+  const int64_t i = GID;
+  if (i < n) v[i] = (uint64_t)i;
+}
 __global__ void k_fill16(uint16_t *__restrict__ v, int64_t n, uint16_t x) {
   const int64_t i = GID;
   if (i < n) v[i] = x;
@@ -198,10 +202,6 @@ __global__ void k_piece_spos(const uint32_t *__restrict__ p_tile, const uint64_t
   p_spos[p] = (uint32_t)(run_start[t] + (sS[p] - tbS[t]));
 }
 __global__ void k_gather64(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx, int64_t n, uint64_t *__restrict__ dst) {
-  const int64_t k = GID;
-  if (k < n) dst[k] = src[idx[k]];
-}
-__global__ void k_gather32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, int64_t n, uint32_t *__restrict__ dst) {
   const int64_t k = GID;
   if (k < n) dst[k] = src[idx[k]];
 }
@@ -740,14 +740,11 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     }
     CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, prodsB, offB, NP + 1, stream));
     if (NP > 0) {
-      // kidx[k] = k as 64-bit "scan" so that k_bounds yields the bins' first piece / one past their last piece
+      // kidx[k] = k as a 64-bit "scan", so that k_bounds yields the bins' first piece / one past their last piece
       // (s1 = kidx, s2 = offB)
-      std::vector<uint64_t> ks((size_t)NP + 1);
-      for (int64_t k = 0; k <= NP; k++) ks[(size_t)k] = (uint64_t)k;
-      GT(hipMemcpyAsync(kidx, ks.data(), ((size_t)NP + 1) * 8, hipMemcpyHostToDevice, stream));
+      LAUNCH(k_iota64, NP + 1, kidx, NP + 1);
       LAUNCH(k_bounds, NP, p_bin_sorted, kidx, offB, NP, bk0, bk1, bo0, bo1);
       LAUNCH(k_piece_off, NP, pB, offB, NP, p_off);
-      GT(hipStreamSynchronize(stream));   // ks dies here
     }
     std::vector<uint64_t> k0((size_t)n_bins), k1((size_t)n_bins), o0((size_t)n_bins), o1((size_t)n_bins);
     GT(hipMemcpyAsync(k0.data(), bk0, (size_t)n_bins * 8, hipMemcpyDeviceToHost, stream));

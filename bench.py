@@ -327,7 +327,8 @@ def main():
         "ms_per_step_raw_values": None if ablation is None else ablation["ms_per_step"],
         "ablation_raw_values": ablation,
         "parity": parity,
-        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": layout, "built_on": A.builder()[0]},
+        "plan": {"name": A.plan()[0], "streamed_bytes_per_launch": A.plan()[1], "layout": layout, "built_on": A.builder()[0],
+                 "placements_timed_at_upload": dict(zip(("tries", "first_ms", "kept_ms"), A.placement()))},
         "gen_seconds": round(t_gen, 2), "upload_seconds": round(t_up, 2), "device": eng.device_name,
     }
     if rehearsal:

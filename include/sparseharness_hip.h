@@ -128,6 +128,9 @@ typedef struct sh_plan_options {
   int32_t build;           /* where the tiled layout is built: 0 default, 1 on the host (threads above), 2 on the device from
                               the CSR arrays (sorts and scans; a failed device step falls back to the host builder).
                               Both produce the same arrays, byte for byte                                    [SH_BUILD=host|device] */
+  int32_t placement_tries; /* where hipMalloc puts the big arrays moves the time of one and the same layout by +-2 %: the
+                              upload times this many placements of them and keeps the fastest (about 5 ms each).
+                              0 default (6 for matrices with >= 2^22 products, else 1), 1 = take the first         [SH_PLACEMENT_TRIES] */
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
@@ -143,6 +146,9 @@ int sh_csr_free(sh_engine *e, sh_csr *m);
 /* Who built the matrix's tiled layout: *where = 0 host, 1 device; note (optional, cap bytes) = why the device builder
  * was not used although asked for, or empty. */
 int sh_csr_builder(const sh_csr *m, int32_t *where, char *note, int64_t cap);
+/* Placement trials of the upload (sh_plan_options::placement_tries): how many placements of the big arrays were timed,
+ * the (+,x) launch time of the first one and of the one kept, in ms (0 when only one was tried). */
+int sh_csr_placement(const sh_csr *m, int32_t *tries, float *first_ms, float *kept_ms);
 int sh_csr_dims(const sh_csr *m, int64_t *rows, int64_t *cols, int64_t *nnz);
 /* Algorithmic bytes of one SpMV over this matrix:
  * 8*nnz + 4*(rows+1) + 4*cols + 4*rows [+ 4*rows if y is read]. */

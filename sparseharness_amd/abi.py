@@ -25,7 +25,7 @@ class sh_launch(C.Structure):
 class sh_plan_options(C.Structure):
     """Plan options of sh_csr_upload_ex (field comments: include/sparseharness_hip.h)."""
     _fields_ = [("plan", C.c_int32), ("autotune", C.c_int32), ("value_coding", C.c_int32), ("build_threads", C.c_int32),
-                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32), ("or_and_bits", C.c_int32), ("build", C.c_int32)]
+                ("heavy_per_tile", C.c_int32), ("chunk", C.c_int32), ("xcd_order", C.c_int32), ("fold", C.c_int32), ("or_and_bits", C.c_int32), ("build", C.c_int32), ("placement_tries", C.c_int32)]
 
 
 class sh_row_pieces(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "sh_csr_describe": (_int, [_vp, C.c_char_p, C.c_size_t]),
     "sh_csr_footprint": (_int, [_vp, C.POINTER(_u64)]),
     "sh_csr_builder": (_int, [_vp, C.POINTER(_i32), C.c_char_p, _i64]),
+    "sh_csr_placement": (_int, [_vp, C.POINTER(_i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sh_vec_alloc": (_int, [_vp, _i64, _pp]),
     "sh_vec_wrap": (_int, [_vp, _vp, _i64, _pp]),
     "sh_vec_free": (_int, [_vp, _vp]),

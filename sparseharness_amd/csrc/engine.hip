@@ -88,6 +88,8 @@ struct sh_csr {
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
   uint32_t round = 0;                         // reporting launches so far
   bool built_on_device = false;               // the tiled layout was built by plan_gpu.hip
+  int placement_tries = 1;                    // placements of the big arrays timed at upload (tune_placement)
+  float placement_ms[2] = {0, 0};             // [first placement, the one kept]
   bool skip_minplus = false;                  // every |value| < 2^103: FLT_MAX + |a| == FLT_MAX, so tiles of unreached x words may be skipped
   std::string build_note;                     // why the device builder was not used / fell back (empty: nothing to say)
 };
@@ -813,6 +815,75 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
   m->tuned_ms[1] = ms[PLAN_TILED];
 }
 
+// Where hipMalloc happens to put the big arrays moves the SpMV time of one and the same layout by +-2 % (stable for the
+// life of the allocation: profiles/r03_placement_probe_*.json; no alignment or stride rule was found behind it).  So the
+// upload of a large matrix tries `tries` placements of the four big streams -- the product array, the column codes, the
+// value codes and the slots -- times a (+,x) launch pair on each (the faster of two after a warm-up, as autotune_plan)
+// and keeps the fastest; the others are freed.  All candidates stay allocated until the choice is made, or the allocator
+// would hand the same place out again.  Costs about 5 ms and one copy of the arrays per try, at upload only.
+static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
+  if (tries <= 1 || m->plan != PLAN_TILED || m->n_bins <= 0 || m->n_chunks <= 0) return;
+  sh_vec xv, ov;
+  if (hipMalloc(&xv.d, (size_t)std::max<int64_t>(m->cols, 1) * 4) != hipSuccess) return;
+  if (hipMalloc(&ov.d, (size_t)std::max<int64_t>(m->rows, 1) * 4) != hipSuccess) { (void)hipFree(xv.d); return; }
+  xv.n = m->cols; ov.n = m->rows;
+  (void)hipMemsetAsync(xv.d, 0, (size_t)std::max<int64_t>(m->cols, 1) * 4, e->stream);
+  const bool coded = m->n_vdict != 0;
+  struct Slot { void **field; size_t bytes; bool copy; };
+  const Slot slots[4] = {
+      {(void **)&m->d_P, (size_t)std::max<int64_t>(m->p_len, 4) * 4 + 16, false},   // (rewritten by every launch)
+      {(void **)&m->d_tcol, (size_t)m->stream_len * 2 + SLACK_WIDE, true},
+      {coded ? (void **)&m->d_tcode : (void **)&m->d_tval,
+       coded ? (size_t)(m->code_bits == 4 ? m->stream_len / 2 : m->stream_len) + SLACK_TCODE : (size_t)m->stream_len * 4 + SLACK_WIDE, true},
+      {(void **)&m->d_pslot, (size_t)m->p_len * 2 + SLACK_WIDE, true}};
+  const float one = 1.0f, zero = 0.0f;
+  auto time_it = [&]() -> float {
+    float best = -1.f;
+    for (int rep = 0; rep < 3; rep++) {
+      float t = 0;
+      if (hipEventRecord(e->ev0, e->stream) != hipSuccess ||
+          dispatch(e, SH_PLUS_TIMES_F32, m, &xv, nullptr, &one, &zero, &ov, StepDev{nullptr, nullptr, 0, 0.0}) != SH_OK ||
+          hipEventRecord(e->ev1, e->stream) != hipSuccess || hipEventSynchronize(e->ev1) != hipSuccess ||
+          hipEventElapsedTime(&t, e->ev0, e->ev1) != hipSuccess)
+        return -1.f;
+      if (rep > 0 && (best < 0 || t < best)) best = t;
+    }
+    return best;
+  };
+  struct Set { void *p[4]; float ms; };
+  std::vector<Set> sets;
+  Set cur{{*slots[0].field, *slots[1].field, *slots[2].field, *slots[3].field}, time_it()};
+  sets.push_back(cur);
+  size_t best = 0;
+  for (int t = 1; t < tries && sets[0].ms > 0; t++) {
+    Set fresh{{nullptr, nullptr, nullptr, nullptr}, -1.f};
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++) {
+      ok = hipMalloc(&fresh.p[i], slots[i].bytes) == hipSuccess;
+      if (ok && slots[i].copy)
+        ok = hipMemcpyAsync(fresh.p[i], sets[0].p[i], slots[i].bytes, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipStreamSynchronize(e->stream);
+      for (void *q : fresh.p) if (q) (void)hipFree(q);
+      break;
+    }
+    for (int i = 0; i < 4; i++) *slots[i].field = fresh.p[i];
+    fresh.ms = time_it();
+    sets.push_back(fresh);
+    if (fresh.ms > 0 && fresh.ms < sets[best].ms) best = sets.size() - 1;
+  }
+  (void)hipStreamSynchronize(e->stream);
+  for (int i = 0; i < 4; i++) *slots[i].field = sets[best].p[i];
+  for (size_t k = 0; k < sets.size(); k++)
+    if (k != best)
+      for (void *q : sets[k].p) (void)hipFree(q);
+  m->placement_tries = (int)sets.size();
+  m->placement_ms[0] = sets[0].ms; m->placement_ms[1] = sets[best].ms;
+  (void)hipFree(xv.d);
+  (void)hipFree(ov.d);
+}
+
 static int choose_plan(const sh_plan_options &opt, int64_t cols, int64_t nnz) {
   if (opt.plan == 1) return PLAN_STREAM;
   if (opt.plan == 2) return PLAN_TILED;
@@ -874,6 +945,7 @@ void sh_plan_options_from_env(sh_plan_options *o) {
   if (const char *v = getenv("SH_XCD_ORDER")) o->xcd_order = v[0] != '0';
   if (const char *v = getenv("SH_FOLD")) o->fold = v[0] != '0';
   num("SH_OR_AND_BITS", o->or_and_bits);
+  num("SH_PLACEMENT_TRIES", o->placement_tries);
   if (const char *v = getenv("SH_BUILD")) o->build = !strcmp(v, "host") ? 1 : ((!strcmp(v, "device") || !strcmp(v, "gpu")) ? 2 : 0);
 }
 
@@ -1099,6 +1171,13 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
 #undef HIP_TRY_M
   if (tune)
     autotune_plan(e, m);   // frees the arrays of the plan that lost
+  {
+    // placements of the big arrays to try: the option, else six for a matrix whose product array has >= 2^22 words
+    // (eight fresh processes each, same box: 1 try 0.4476 ms, 3 tries 0.4384, 6 tries 0.4331; upload 0.137 / 0.144 / 0.152 s:
+    // profiles/r03_ab_placement_tries.log)
+    const int tries = opt.placement_tries > 0 ? opt.placement_tries : (m->plan == PLAN_TILED && m->p_len >= ((int64_t)1 << 22) ? 6 : 1);
+    tune_placement(e, m, tries);
+  }
   if (bits_on_device && !tiled) m->built_on_device = true;   // (a matrix whose only device-built layout is the bit-blocked one)
   *out = m;
   return SH_OK;
@@ -1133,6 +1212,15 @@ int sh_csr_builder(const sh_csr *m, int32_t *where, char *note, int64_t cap) {
     return SH_EINVAL;
   if (where) *where = m->built_on_device ? 1 : 0;
   if (note && cap > 0) snprintf(note, (size_t)cap, "%s", m->build_note.c_str());
+  return SH_OK;
+}
+
+int sh_csr_placement(const sh_csr *m, int32_t *tries, float *first_ms, float *kept_ms) {
+  if (!m)
+    return SH_EINVAL;
+  if (tries) *tries = m->placement_tries;
+  if (first_ms) *first_ms = m->placement_ms[0];
+  if (kept_ms) *kept_ms = m->placement_ms[1];
   return SH_OK;
 }
 

@@ -100,6 +100,12 @@ class CsrMatrix:
         self.engine._chk(abi.load().sh_csr_builder(self.h, C.byref(w), note, len(note)))
         return ("device" if w.value else "host"), note.value.decode()
 
+    def placement(self):
+        """(placements of the big arrays timed at upload, ms of the first, ms of the one kept)."""
+        n, a, b = C.c_int32(), C.c_float(), C.c_float()
+        self.engine._chk(abi.load().sh_csr_placement(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, round(a.value, 4), round(b.value, 4)
+
     def free(self):
         if self.h is not None:
             abi.load().sh_csr_free(self.engine.h, self.h)

@@ -855,7 +855,11 @@ static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
   Set cur{{*slots[0].field, *slots[1].field, *slots[2].field, *slots[3].field}, time_it()};
   sets.push_back(cur);
   size_t best = 0;
+  size_t set_bytes = 0;
+  for (const Slot &sl : slots) set_bytes += sl.bytes;
   for (int t = 1; t < tries && sets[0].ms > 0; t++) {
+    size_t fr = 0, tot = 0;   // (the candidates are all held until the end: never take more than half of what is free)
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * set_bytes + ((size_t)1 << 30)) break;
     Set fresh{{nullptr, nullptr, nullptr, nullptr}, -1.f};
     bool ok = true;
     for (int i = 0; i < 4 && ok; i++) {
@@ -874,6 +878,12 @@ static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
     if (fresh.ms > 0 && fresh.ms < sets[best].ms) best = sets.size() - 1;
   }
   (void)hipStreamSynchronize(e->stream);
+#ifdef SH_PLAN_EMULATE
+  if (getenv("SH_PLACEMENT_LOG"))
+    for (size_t k = 0; k < sets.size(); k++)
+      fprintf(stderr, "[placement] %2zu  P %p  tcol %p  tcode %p  pslot %p  %.4f ms%s\n", k, sets[k].p[0], sets[k].p[1], sets[k].p[2], sets[k].p[3],
+              sets[k].ms, k == best ? "  <- kept" : "");
+#endif
   for (int i = 0; i < 4; i++) *slots[i].field = sets[best].p[i];
   for (size_t k = 0; k < sets.size(); k++)
     if (k != best)
@@ -1172,10 +1182,11 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   if (tune)
     autotune_plan(e, m);   // frees the arrays of the plan that lost
   {
-    // placements of the big arrays to try: the option, else six for a matrix whose product array has >= 2^22 words
-    // (eight fresh processes each, same box: 1 try 0.4476 ms, 3 tries 0.4384, 6 tries 0.4331; upload 0.137 / 0.144 / 0.152 s:
-    // profiles/r03_ab_placement_tries.log)
-    const int tries = opt.placement_tries > 0 ? opt.placement_tries : (m->plan == PLAN_TILED && m->p_len >= ((int64_t)1 << 22) ? 6 : 1);
+    // placements of the big arrays to try: the option, else twelve for a matrix whose product array has >= 2^22 words
+    // (eight fresh processes each, same box: 1 try 0.4476 ms, 3 tries 0.4384, 6 tries 0.4331, upload 0.137 / 0.144 / 0.152 s:
+    // profiles/r03_ab_placement_tries.log; sixteen placements in one process: 0.4166 .. 0.4477 ms, median 0.4348:
+    // profiles/r03_placement_log_16_tries.txt)
+    const int tries = opt.placement_tries > 0 ? opt.placement_tries : (m->plan == PLAN_TILED && m->p_len >= ((int64_t)1 << 22) ? 12 : 1);
     tune_placement(e, m, tries);
   }
   if (bits_on_device && !tiled) m->built_on_device = true;   // (a matrix whose only device-built layout is the bit-blocked one)

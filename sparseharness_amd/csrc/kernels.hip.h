@@ -11,6 +11,7 @@
 //      no padded ELLPACK, no global temp buffer, no re-reads.  Described next.
 //   B  "x-tiled two-phase": big x with scattered columns: x tiles are staged in
 //      LDS and the products re-binned through HBM.  Described further down.
+//   (C, for SH_OR_AND_I32 launches only: the bit-blocked layout of bits.hip.h -- x as a bitmap, 4 bytes per entry.)
 //
 // Plan A schedule (built on upload): the row range is cut into
 //   * stream blocks: consecutive rows whose non-zeros (<= NNZ_BLK, counted

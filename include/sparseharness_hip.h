@@ -129,8 +129,8 @@ typedef struct sh_plan_options {
                               the CSR arrays (sorts and scans; a failed device step falls back to the host builder).
                               Both produce the same arrays, byte for byte                                    [SH_BUILD=host|device] */
   int32_t placement_tries; /* where hipMalloc puts the big arrays moves the time of one and the same layout by +-2 %: the
-                              upload times this many placements of them and keeps the fastest (about 2.5 ms each for
-                              a 200 M-entry matrix). 0 default (12 for matrices with >= 2^22 products, else 1), 1 = take the first         [SH_PLACEMENT_TRIES] */
+                              upload times this many placements of them and keeps the fastest (about 3 ms each for
+                              a 200 M-entry matrix). 0 default (6 for matrices with >= 2^22 products, else 1), 1 = take the first         [SH_PLACEMENT_TRIES] */
 } sh_plan_options;
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);

@@ -818,7 +818,7 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
 // Where hipMalloc happens to put the big arrays moves the SpMV time of one and the same layout by +-2 % (stable for the
 // life of the allocation: profiles/r03_placement_probe_*.json; no alignment or stride rule was found behind it).  So the
 // upload of a large matrix tries `tries` placements of the four big streams -- the product array, the column codes, the
-// value codes and the slots -- times a (+,x) launch pair on each (the faster of two after a warm-up, as autotune_plan)
+// value codes and the slots -- times (+,x) launch pairs on each (four back to back after a warm-up)
 // and keeps the fastest; the others are freed.  All candidates stay allocated until the choice is made, or the allocator
 // would hand the same place out again.  Costs about 5 ms and one copy of the arrays per try, at upload only.
 static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
@@ -837,18 +837,19 @@ static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
        coded ? (size_t)(m->code_bits == 4 ? m->stream_len / 2 : m->stream_len) + SLACK_TCODE : (size_t)m->stream_len * 4 + SLACK_WIDE, true},
       {(void **)&m->d_pslot, (size_t)m->p_len * 2 + SLACK_WIDE, true}};
   const float one = 1.0f, zero = 0.0f;
-  auto time_it = [&]() -> float {
-    float best = -1.f;
-    for (int rep = 0; rep < 3; rep++) {
-      float t = 0;
-      if (hipEventRecord(e->ev0, e->stream) != hipSuccess ||
-          dispatch(e, SH_PLUS_TIMES_F32, m, &xv, nullptr, &one, &zero, &ov, StepDev{nullptr, nullptr, 0, 0.0}) != SH_OK ||
-          hipEventRecord(e->ev1, e->stream) != hipSuccess || hipEventSynchronize(e->ev1) != hipSuccess ||
-          hipEventElapsedTime(&t, e->ev0, e->ev1) != hipSuccess)
-        return -1.f;
-      if (rep > 0 && (best < 0 || t < best)) best = t;
-    }
-    return best;
+  auto time_it = [&]() -> float {   // one warm-up, then four launch pairs back to back as one interval (the steady state of a loop)
+    constexpr int REPS = 4;
+    float t = 0;
+    const StepDev none{nullptr, nullptr, 0, 0.0};
+    if (dispatch(e, SH_PLUS_TIMES_F32, m, &xv, nullptr, &one, &zero, &ov, none) != SH_OK ||
+        hipEventRecord(e->ev0, e->stream) != hipSuccess)
+      return -1.f;
+    for (int rep = 0; rep < REPS; rep++)
+      if (dispatch(e, SH_PLUS_TIMES_F32, m, &xv, nullptr, &one, &zero, &ov, none) != SH_OK) return -1.f;
+    if (hipEventRecord(e->ev1, e->stream) != hipSuccess || hipEventSynchronize(e->ev1) != hipSuccess ||
+        hipEventElapsedTime(&t, e->ev0, e->ev1) != hipSuccess)
+      return -1.f;
+    return t / REPS;
   };
   struct Set { void *p[4]; float ms; };
   std::vector<Set> sets;
@@ -1182,11 +1183,11 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
   if (tune)
     autotune_plan(e, m);   // frees the arrays of the plan that lost
   {
-    // placements of the big arrays to try: the option, else twelve for a matrix whose product array has >= 2^22 words
-    // (eight fresh processes each, same box: 1 try 0.4476 ms, 3 tries 0.4384, 6 tries 0.4331, upload 0.137 / 0.144 / 0.152 s:
-    // profiles/r03_ab_placement_tries.log; sixteen placements in one process: 0.4166 .. 0.4477 ms, median 0.4348:
-    // profiles/r03_placement_log_16_tries.txt)
-    const int tries = opt.placement_tries > 0 ? opt.placement_tries : (m->plan == PLAN_TILED && m->p_len >= ((int64_t)1 << 22) ? 12 : 1);
+    // placements of the big arrays to try: the option, else six for a matrix whose product array has >= 2^22 words.
+    // Eight fresh processes per setting, one box each time (profiles/r03_ab_placement_tries*.log): 1 / 3 / 6 tries
+    // 0.4476 / 0.4384 / 0.4331 ms; on another box 1 / 6 / 12 / 24 tries 0.4456 / 0.4413 / 0.4391 / 0.4417 (means): a trial
+    // predicts the steady state of the caller's loop (other x and out vectors) only in part, and past six nothing is gained.
+    const int tries = opt.placement_tries > 0 ? opt.placement_tries : (m->plan == PLAN_TILED && m->p_len >= ((int64_t)1 << 22) ? 6 : 1);
     tune_placement(e, m, tries);
   }
   if (bits_on_device && !tiled) m->built_on_device = true;   // (a matrix whose only device-built layout is the bit-blocked one)

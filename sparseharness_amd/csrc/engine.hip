@@ -1479,6 +1479,17 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       HIP_TRY(e, hipGetLastError());
     }
 #ifdef SH_STATS
+    if (getenv("SH_STATS_DUMP") && A->n_bins > 0) {   // where the two roles of phase 2 spent their cycles (wave 0 of each role, per workgroup)
+      (void)hipStreamSynchronize(e->stream);
+      std::vector<uint64_t> pf(256 * 16);
+      (void)hipMemcpyFromSymbol(pf.data(), HIP_SYMBOL(g_p2_prof), pf.size() * 8);
+      const int G = std::min(A->n_bins, 256);
+      double a[16] = {0};
+      for (int w = 0; w < G; w++) for (int k = 0; k < 16; k++) a[k] += (double)pf[(size_t)w * 16 + k] / G;
+      fprintf(stderr, "[stats] phase 2 per workgroup (%d, %.1f bins each), shader cycles: loaders total %.0f, in vmcnt waits %.0f (%.1f %%), in barriers %.0f (%.1f %%), issuing/scattering %.0f | "
+                      "reducers total %.0f, in barriers %.0f (%.1f %%), reducing %.0f (one-lane pass %.0f, 8-lane rows %.0f, 64-lane rows %.0f)\n",
+              G, a[3], a[0], a[1], 100 * a[1] / a[0], a[2], 100 * a[2] / a[0], a[0] - a[1] - a[2], a[4], a[5], 100 * a[5] / a[4], a[6], a[8], a[9], a[10]);
+    }
     if (getenv("SH_STATS_DUMP") && p1_stats) {
       const int nch = A->n_chunks;
       std::vector<uint64_t> hs((size_t)nch * 5);

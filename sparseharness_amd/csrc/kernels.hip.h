@@ -164,8 +164,8 @@ static __global__ void report_all_pieces(StepDev st) {
 // never serialises the workgroup and a row's summation order is the same
 // under every plan:
 //   len <= 24    1 lane, sequential in stored order
-//   len <= 256   8 lanes  (stride-8 partial sums, then xor-tree 4,2,1)
-//   len <= 4096  64 lanes (stride-64 partial sums, then xor-tree 32..1)
+//   len <= 256   8 lanes  (stride-8 partial sums, then a DPP tree into the group's last lane)
+//   len <= 4096  64 lanes (stride-64 partial sums, then a DPP tree into lane 63)
 //   longer       the whole workgroup (stride-NT sums, wave trees, then waves in order)
 // Rows are classified by one pass that finishes the short ones on the spot
 // and appends the others to three LDS work lists.
@@ -173,9 +173,41 @@ static __global__ void report_all_pieces(StepDev st) {
 #define SH_RL_SHORT 24
 #endif
 constexpr int RL_SHORT = SH_RL_SHORT, RL_MID = 256, RL_WAVE = 4096;
+#ifndef SH_RL_BATCH
+#define SH_RL_BATCH 8
+#endif
+constexpr int RL_BATCH = SH_RL_BATCH;          // products of a one-lane row read per LDS round trip
+constexpr int RL_BATCH8 = 4, RL_BATCH64 = 8;   // the same for the lanes of an 8-lane / a 64-lane row
+constexpr int RL_PAD = 8;                      // spare words behind a product array: a one-lane batch starts inside its row and may read up to 7 words past its (and the image's) end; word 0 of them is where phase 2's loaders drop padding products
 // rp[] entries may carry RP_SKIP: the row is produced elsewhere (heavy rows of the tiled plan)
 // and must be neither written nor tested here.  Offsets stay below 2^30.
 constexpr int32_t RP_SKIP = 1 << 30, RP_MASK = RP_SKIP - 1;
+
+// Cross-lane sums of the cooperative rows in DPP (no LDS round trip per step, unlike __shfl_xor = ds_bpermute): the
+// partial sums of a group of 8 lanes end up in the group's LAST lane (row_shr 4, 2, 1 inside a row of 16 lanes), those
+// of a wave in lane 63 (row_shr 8, 4, 2, 1, then row_bcast:15 / :31).  Lanes whose source lies outside the DPP row
+// receive the identity.  The order of the additions depends on the lane positions alone.
+template <class SR, int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ typename SR::T dpp_fold(typename SR::T t) {
+  using T = typename SR::T;
+  const T up = from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp((int)to_bits<T>(SR::identity()), (int)to_bits<T>(t), CTRL, ROW_MASK, 0xF, false));
+  return SR::add(t, up);
+}
+template <class SR>
+__device__ __forceinline__ typename SR::T sum_to_last_of_8(typename SR::T t) {
+  t = dpp_fold<SR, 0x114>(t);
+  t = dpp_fold<SR, 0x112>(t);
+  return dpp_fold<SR, 0x111>(t);
+}
+template <class SR>
+__device__ __forceinline__ typename SR::T sum_to_lane_63(typename SR::T t) {
+  t = dpp_fold<SR, 0x118>(t);
+  t = dpp_fold<SR, 0x114>(t);
+  t = dpp_fold<SR, 0x112>(t);
+  t = dpp_fold<SR, 0x111>(t);
+  t = dpp_fold<SR, 0x142, 0xA>(t);      // row_bcast:15 into rows 1 and 3
+  return dpp_fold<SR, 0x143, 0xC>(t);   // row_bcast:31 into rows 2 and 3
+}
 
 template <int NT, int NNZ_CAP> struct ReduceScratch {
   uint16_t lst8[NNZ_CAP / (RL_SHORT + 1) + 1];
@@ -193,7 +225,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
                                             const uint32_t *__restrict__ y,
                                             typename SR::T alpha, typename SR::T beta, bool use_y,
                                             uint32_t *__restrict__ out, const StepDev &st,
-                                            uint32_t *stage = nullptr) {
+                                            uint32_t *stage = nullptr, uint64_t *prof = nullptr) {
   using T = typename SR::T;
   // stage != nullptr (workgroup-uniform): the row's dot goes to stage[row] in LDS and the caller
   // applies the epilogue later in a coalesced pass (used when the epilogue reads y / prev: those
@@ -204,14 +236,29 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
     else
       finish_row<SR>(r0 + row, acc, y, alpha, beta, use_y, out, st);
   };
+  // The sums below read their products a batch at a time -- all reads of a batch are issued before the first is
+  // used -- instead of one LDS round trip per product: a wave's time in a dependent read / add loop is the LDS
+  // latency times its longest row (phase 2 of the tiled plan spent 78 % of its cycles in these loops:
+  // profiles/r04_phase2_role_profile.log).  What a batch reads past the row's end is not added; the order of the
+  // additions is the stored order, as before.  (prof: SH_STATS builds, cycles of wave 0 in {MID barrier, one-lane
+  // pass, 8-lane rows, 64-lane rows}.)
+  SH_STAT(const uint64_t pf_r0 = __builtin_amdgcn_s_memtime();)
   for (int row = tid; row < nr; row += NT) {
     const int s = rp[row] & RP_MASK, len = (rp[row + 1] & RP_MASK) - s;
     if (rp[row] & RP_SKIP)
       continue;
     if (len <= RL_SHORT) {
       T acc = SR::identity();
-      for (int j = 0; j < len; j++)
-        acc = SR::add(acc, from_bits<T>(prod[s + j]));
+      for (int j0 = 0; j0 < len; j0 += RL_BATCH) {
+        uint32_t v[RL_BATCH];
+#pragma unroll
+        for (int k = 0; k < RL_BATCH; k++)
+          v[k] = prod[s + j0 + k];   // (up to RL_PAD - 1 words past the row: the product arrays carry them)
+#pragma unroll
+        for (int k = 0; k < RL_BATCH; k++)
+          if (j0 + k < len)
+            acc = SR::add(acc, from_bits<T>(v[k]));
+      }
       emit(row, acc);
     } else if (len <= RL_MID) {
       sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
@@ -221,32 +268,48 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       sc.lstB[atomicAdd(&cnt[2], 1)] = (uint16_t)row;
     }
   }
+  SH_STAT(const uint64_t pf_m0 = __builtin_amdgcn_s_memtime(); if (prof) prof[1] += pf_m0 - pf_r0;)
   lds_barrier();
+  SH_STAT(const uint64_t pf_m1 = __builtin_amdgcn_s_memtime(); if (prof) prof[0] += pf_m1 - pf_m0;)
   const int n8 = cnt[0], n64 = cnt[1], nB = cnt[2];
   for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
     const int row = sc.lst8[idx], l = tid & 7;
     const int e = rp[row + 1] & RP_MASK;
     T acc = SR::identity();
-    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 8)
-      acc = SR::add(acc, from_bits<T>(prod[j]));
+    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 8 * RL_BATCH8) {
+      uint32_t v[RL_BATCH8];
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1)
-      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
-    if (l == 0)
+      for (int k = 0; k < RL_BATCH8; k++)
+        v[k] = prod[min(j + 8 * k, e - 1)];   // (clamped into the row: j < e)
+#pragma unroll
+      for (int k = 0; k < RL_BATCH8; k++)
+        if (j + 8 * k < e)
+          acc = SR::add(acc, from_bits<T>(v[k]));
+    }
+    acc = sum_to_last_of_8<SR>(acc);
+    if (l == 7)
       emit(row, acc);
   }
+  SH_STAT(const uint64_t pf_m2 = __builtin_amdgcn_s_memtime(); if (prof) prof[2] += pf_m2 - pf_m1;)
   for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
     const int row = sc.lst64[idx], l = tid & 63;
     const int e = rp[row + 1] & RP_MASK;
     T acc = SR::identity();
-    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 64)
-      acc = SR::add(acc, from_bits<T>(prod[j]));
+    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 64 * RL_BATCH64) {
+      uint32_t v[RL_BATCH64];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-      acc = SR::add(acc, from_bits<T>(__shfl_xor(to_bits<T>(acc), o, 64)));
-    if (l == 0)
+      for (int k = 0; k < RL_BATCH64; k++)
+        v[k] = prod[min(j + 64 * k, e - 1)];
+#pragma unroll
+      for (int k = 0; k < RL_BATCH64; k++)
+        if (j + 64 * k < e)
+          acc = SR::add(acc, from_bits<T>(v[k]));
+    }
+    acc = sum_to_lane_63<SR>(acc);
+    if (l == 63)
       emit(row, acc);
   }
+  SH_STAT(if (prof) prof[3] += __builtin_amdgcn_s_memtime() - pf_m2;)
   for (int idx = 0; idx < nB; idx++) {   // nB is workgroup-uniform
     const int row = sc.lstB[idx];
     const int e = rp[row + 1] & RP_MASK;
@@ -278,7 +341,7 @@ __global__ __launch_bounds__(BS) void spmv_csr_kernel(
   using T = typename SR::T;
   if (gate_closed(st))
     return;
-  __shared__ uint32_t prod[NNZ_BLK];
+  __shared__ uint32_t prod[NNZ_BLK + RL_PAD];
   __shared__ int32_t rp[ROWS_BLK + 1];
   __shared__ ReduceScratch<BS, NNZ_BLK> sc;
   uint32_t *wred = sc.wred;
@@ -588,6 +651,15 @@ __device__ __forceinline__ typename SR::T seg_scan_wave(typename SR::T t, const 
 // VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
 // xs: [TCOLS + 4] words of LDS, ds: [VDICT].
 SH_STAT(__device__ uint64_t *g_p1_stats;)
+// per workgroup of phase 2 (wave 0 of each role, shader cycles): [0] loader total, [1] loader in vmcnt waits, [2] loader in
+// barriers, [3] bins, [4] reducer total, [5] reducer in barriers, [6] reducer in the reduction proper, [7] bins,
+// [8..10] reducer in the one-lane pass / the 8-lane rows / the 64-lane rows
+SH_STAT(__device__ uint64_t g_p2_prof[256 * 16];)
+#ifdef SH_STATS
+#define SH_TIMED(acc, ...) { const uint64_t pf_a = __builtin_amdgcn_s_memtime(); __VA_ARGS__; acc += __builtin_amdgcn_s_memtime() - pf_a; }
+#else
+#define SH_TIMED(acc, ...) { __VA_ARGS__; }
+#endif
 struct NoHook { __device__ void operator()() const {} };
 // staged(): called by every thread right after the barrier that publishes the x tile (SH_STATS builds stamp it).
 template <class SR, int VC, class Hook = NoHook>
@@ -899,7 +971,7 @@ static_assert(TBIN / 4 <= RL_WAVE, "light rows must not reach the workgroup-wide
 
 // LDS of the phase-2 role
 struct P2Lds {
-  uint32_t prod[2][TBIN];
+  uint32_t prod[2][TBIN + RL_PAD];   // [TBIN]: where the loaders drop padding products; the rest: see RL_PAD
   int32_t rp[2][TBIN_ROWS + 1];
   uint32_t dots[TBIN_ROWS];
   ReduceScratch<P2S_RD, TBIN> sc;
@@ -991,9 +1063,17 @@ __device__ __forceinline__ void tiled_phase2_run(
       const v2u32 *S4 = reinterpret_cast<const v2u32 *>(pslot + bn.pstart);
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
+#if defined(SH_DBG_P2) && (SH_DBG_P2 & 2)   // tools builds (wrong results): the slot words of a bin come out of one line
+        async_load(s[k], S4 + (tid & 15));
+#else
         async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
+#endif
         // (clamped: a stale register must not fault)
+#if defined(SH_DBG_P2) && (SH_DBG_P2 & 1)   // tools builds (wrong results): P read bin-major, i.e. sequentially
+        const int32_t pg = max(0, min(bn.pstart / 4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
+#else
         const int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
+#endif
         async_load(p[k], P4 + pg);
       }
     };
@@ -1007,14 +1087,24 @@ __device__ __forceinline__ void tiled_phase2_run(
     auto scatter = [&](uint32_t *img, const RowBin &bn, int quarter, const v4u32 (&p)[P2S_K], const v2u32 (&s)[P2S_K]) {
       const int n4 = bn.n / 4;
 #pragma unroll
-      for (int k = 0; k < P2S_K; k++)
-        if (quarter * P2S_Q + k * P2S_LD + tid < n4) {
-          const uint32_t s0 = s[k].x & 0xFFFFu, s1 = s[k].x >> 16, s2 = s[k].y & 0xFFFFu, s3 = s[k].y >> 16;
-          if (s0 != TSLOT_PAD) img[s0] = p[k].x;
-          if (s1 != TSLOT_PAD) img[s1] = p[k].y;
-          if (s2 != TSLOT_PAD) img[s2] = p[k].z;
-          if (s3 != TSLOT_PAD) img[s3] = p[k].w;
-        }
+      for (int k = 0; k < P2S_K; k++) {
+        // Branch-free (6 -> 3 instructions per product: v_min_u32_sdwa, v_lshl_add_u32, ds_write_b32): a padding product --
+        // slot TSLOT_PAD -- lands in the spare word behind the image, and a lane past the bin's last group (its loads
+        // were clamped) drops what it loaded the same way.
+#if defined(SH_DBG_P2) && (SH_DBG_P2 & 2)
+        const uint32_t gq = (uint32_t)(quarter * P2S_Q + k * P2S_LD + tid) * 4u;
+        const uint32_t s0 = (s[k].x & 3u) + gq, s1 = s0 ^ 1u, s2 = s0 ^ 2u, s3 = s0 ^ 3u;
+        (void)n4;
+#else
+        const bool in_bin = quarter * P2S_Q + k * P2S_LD + tid < n4;
+        const uint32_t sx = in_bin ? s[k].x : 0xFFFFFFFFu, sy = in_bin ? s[k].y : 0xFFFFFFFFu;
+        const uint32_t s0 = sx & 0xFFFFu, s1 = sx >> 16, s2 = sy & 0xFFFFu, s3 = sy >> 16;
+#endif
+        img[min(s0, (uint32_t)TBIN)] = p[k].x;
+        img[min(s1, (uint32_t)TBIN)] = p[k].y;
+        img[min(s2, (uint32_t)TBIN)] = p[k].z;
+        img[min(s3, (uint32_t)TBIN)] = p[k].w;
+      }
     };
     RowBin cur = bin_at(0), nxt = bin_at(1), nxt2 = bin_at(2);
     // step q + d (d = 2, 3) seen from step s of the current bin: which bin, which step in it
@@ -1038,36 +1128,39 @@ __device__ __forceinline__ void tiled_phase2_run(
       fetch_rec(bin_of(3), 3 % P2S_NS);                    // (for the first step of the loop)
       issue_ps(bin_of(1), 1 % P2S_NS, g[1], p[1], sl[1]);
     }
+    SH_STAT(uint64_t pf_wait = 0, pf_bar = 0; const uint64_t pf_t0 = __builtin_amdgcn_s_memtime();)
     for (int j = 0; j <= nb; j++) {
       if (j < nb) {
         uint32_t *img = prod[j & 1];
 #pragma unroll
         for (int s = 0; s < P2S_NS; s++) {
           const int a = s & 1;
-          wait8(p[a], sl[a], g[a]);                        // P/S(q) and the piece words of q+2 have landed
+          SH_TIMED(pf_wait, wait8(p[a], sl[a], g[a]))      // P/S(q) and the piece words of q+2 have landed
           scatter(img, cur, s, p[a], sl[a]);
           issue_gs(bin_of(s + 3), g[a ^ 1]);                          // piece words of step q+3 (records fetched a step ago)
           fetch_rec(bin_of(s + 4), (s + 4) % P2S_NS);                 // records of step q+4
           issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
           if (s == P2S_NS / 2 - 1)
-            lds_barrier();   // MID
+            SH_TIMED(pf_bar, lds_barrier())   // MID
         }
         cur = nxt;
         nxt = nxt2;
         nxt2 = bin_at(j + 3);
       } else {
-        lds_barrier();   // MID of the last reduction
+        SH_TIMED(pf_bar, lds_barrier())   // MID of the last reduction
       }
       if (staged)
-        lds_barrier();   // MID2
-      lds_barrier();     // END
+        SH_TIMED(pf_bar, lds_barrier())   // MID2
+      SH_TIMED(pf_bar, lds_barrier())     // END
       report(j);         // (bins 0 .. j-1 of this workgroup are reduced)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead loads must land before the wave moves on
+    SH_STAT(if (tid == 0) { uint64_t *S = g_p2_prof + (blockIdx.x & 255) * 16; S[0] = __builtin_amdgcn_s_memtime() - pf_t0; S[1] = pf_wait; S[2] = pf_bar; S[3] = (uint64_t)nb; })
   } else {
     // ------------------------------------------------------------------ reducers
     const int rt = tid - P2S_LD;
     RowBin prev = bin_at(0);
+    SH_STAT(uint64_t pf_bar = 0, pf_red = 0, pf_in[4] = {0, 0, 0, 0}; const uint64_t pf_t0 = __builtin_amdgcn_s_memtime();)
     for (int j = 0; j <= nb; j++) {
       const RowBin cur = bin_at(j);
       // row offsets of the bin being streamed now (needed by the next reduction)
@@ -1096,8 +1189,8 @@ __device__ __forceinline__ void tiled_phase2_run(
             }
           }
         }
-        reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
-                                               alpha, beta, use_y, out, st, staged ? dots : nullptr);   // contains MID
+        SH_TIMED(pf_red, reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
+                                               alpha, beta, use_y, out, st, staged ? dots : nullptr SH_STAT(, pf_in)))   // contains MID
         if (staged) {
           lds_barrier();   // MID2
           const int32_t *rpp = rp[(j - 1) & 1];
@@ -1128,10 +1221,11 @@ __device__ __forceinline__ void tiled_phase2_run(
             rp[j & 1][rt + k * P2S_RD] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)cur.csr0) | ((v >> 31) ? RP_SKIP : 0);
           }
       }
-      lds_barrier();     // END
+      SH_TIMED(pf_bar, lds_barrier())     // END
       report(j);
       prev = cur;
     }
+    SH_STAT(if (rt == 0) { uint64_t *S = g_p2_prof + (blockIdx.x & 255) * 16; S[4] = __builtin_amdgcn_s_memtime() - pf_t0; S[5] = pf_bar + pf_in[0]; S[6] = pf_red - pf_in[0]; S[7] = (uint64_t)nb; S[8] = pf_in[1]; S[9] = pf_in[2]; S[10] = pf_in[3]; })
   }
 }
 

@@ -1,8 +1,9 @@
 #!/bin/bash
 # tools/kstats_arms.sh <outdir> "name|LIB|ENV=VAL ENV=VAL" ... -- per-kernel rocprofv3 averages of a short bench.py run for
 # several engine builds / knob settings on one box (LIB: path under sparseharness_amd/, or "head").  bench args: $BENCH_ARGS
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"; [ -n "$1" ] || { echo "usage: $0 <outdir> ..." >&2; exit 2; }
 root=$GRAFT_REPO_ROOT; outroot=$root/gpurun_out/$1; shift
-rm -rf $outroot; mkdir -p $outroot; cd /tmp; export TMPDIR=/tmp
+rm -rf "$outroot"; mkdir -p "$outroot"; cd /tmp; export TMPDIR=/tmp SH_PLACEMENT_TRIES=${SH_PLACEMENT_TRIES:-1}   # (one placement: the averages hold the timed launches only)
 for arm in "$@"; do
   IFS='|' read -r name lib envs <<< "$arm"
   out=$outroot/$name; mkdir -p $out

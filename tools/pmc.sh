@@ -3,8 +3,9 @@
 # (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # Writes <outdir>/traffic.json: one record {workload, layout, n_gpus, bytes, ...} for profiles/measured_traffic.json
 # (bench.py echoes it as roofline.traffic only for exactly that workload and device layout).
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"; [ -n "$1" ] || { echo "usage: $0 <outdir> ..." >&2; exit 2; }
 name=$1; out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
-rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp   # a fresh directory per run
+rm -rf "$out"; mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp   # a fresh directory per run
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ablation "$@" > $out/$ctr.json 2> $out/$ctr.err
 done

@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/pmc_sq.sh <outdir> "<counters>" [bench args] -- SQ counters per kernel (one pass)
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"; [ -n "$1" ] || { echo "usage: $0 <outdir> ..." >&2; exit 2; }
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; ctrs="$2"; shift; shift
-rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp   # a fresh directory per run
+rm -rf "$out"; mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp   # a fresh directory per run
 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ablation "$@" > $out/bench.json 2> $out/err.log
 python3 - $out <<'PY'
 import csv, glob, os, sys, collections

@@ -135,8 +135,11 @@ typedef struct sh_plan_options {
 void sh_plan_options_default(sh_plan_options *o);
 void sh_plan_options_from_env(sh_plan_options *o);
 /* Prefix sum (rows + 1 values, work_prefix[0] = 0) of the HBM bytes the engine expects to move per row under the
- * plan it would choose for a matrix of these dimensions: what row-range sharding across GPUs balances on (the
- * reference has one device, inc/harness.h:419).  Host-only: needs no device.  opt == NULL: the defaults. */
+ * plan it would choose for a matrix of `cols` columns and `nnz` entries -- nnz is the size the PLAN is chosen for
+ * (what one rank uploads, i.e. its share of the matrix), not necessarily row_ptr[rows]: what row-range sharding
+ * across GPUs balances on (the reference has one device, inc/harness.h:419).  The weights describe the x-tiled and
+ * the CSR-stream plan; they say nothing about the bit-blocked (or,and) layout (4 B per live entry: balance on the
+ * entries).  Host-only: needs no device.  opt == NULL: the defaults. */
 int sh_plan_row_work(int64_t rows, int64_t cols, int64_t nnz, const int32_t *row_ptr, const sh_plan_options *opt,
                      uint64_t *work_prefix);
 int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz,
@@ -237,6 +240,12 @@ typedef struct sh_row_pieces {
 int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x, const sh_vec *y,
                         const void *alpha, const void *beta, sh_vec *out, const sh_row_pieces *pieces, double delta,
                         int32_t *changed_flag_device, uint32_t *round, const volatile uint32_t **done_words);
+
+/* Diagnosis for a caller whose wait on *done_words timed out (no counterpart in the reference): host_words[8] = the
+ * words the caller polls, *round = the latest reporting launch, *expected = arrivals per piece it waits for,
+ * arrivals[8] = the device-side arrival counters of that launch, read through a stream of the call's own so that a
+ * launch that never ends cannot block the question (0xFFFFFFFF each when even that copy did not finish in 2 s). */
+int sh_csr_piece_state(sh_engine *e, sh_csr *A, uint32_t *arrivals, uint32_t *host_words, uint32_t *expected, uint32_t *round);
 
 int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x,
                const sh_vec *y0, sh_vec *scratch, const void *alpha,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sh_spmv_step": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_double, _vp]),
     "sh_spmv_step_pieces": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(sh_row_pieces), C.c_double, _vp,
                                    C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32))]),
+    "sh_csr_piece_state": (_int, [_vp, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 _lib = None

@@ -87,6 +87,7 @@ struct sh_csr {
   bool bits_only = false;                     // no other plan was built: only SH_OR_AND_I32 launches are served
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
   uint32_t round = 0;                         // reporting launches so far
+  uint32_t last_expected = 0;                 // arrivals per piece the latest reporting launch waits for (sh_csr_piece_state)
   bool built_on_device = false;               // the tiled layout was built by plan_gpu.hip
   int placement_tries = 1;                    // placements of the big arrays timed at upload (tune_placement)
   float placement_ms[2] = {0, 0};             // [first placement, the one kept]
@@ -1647,6 +1648,8 @@ int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x
     // arrivals per piece and launch: one per workgroup of phase 2, or the single one of report_all_pieces
     st.expected = (A->plan == PLAN_TILED && A->n_bins > 0 && !(sr == SH_OR_AND_I32 && A->d_bits_items)) ? (uint32_t)std::min(A->n_bins, e->n_cus) : 1u;
     A->round++;
+    st.round = A->round;
+    A->last_expected = st.expected;
     if (round) *round = A->round;
     if (done_words) *done_words = A->h_done;
   }
@@ -1654,6 +1657,33 @@ int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x
   sh_vec yfull;
   if (y) { yfull = *y; yfull.owned = false; yfull.n = std::max<int64_t>(y->n, A->rows); }
   return dispatch(e, sr, A, x, y ? &yfull : nullptr, alpha, beta, out, st);
+}
+
+// Diagnosis of a piece report that does not arrive (the driver's wait timed out): the host words, what the latest
+// reporting launch expects, and -- read through a stream of its own, so that a launch that never ends cannot block
+// the question -- the device-side arrival counters (0xFFFFFFFF each when the copy itself did not finish in 2 s).
+int sh_csr_piece_state(sh_engine *e, sh_csr *A, uint32_t *arrivals, uint32_t *host_words, uint32_t *expected, uint32_t *round) {
+  if (!e || !A || !arrivals || !host_words)
+    return fail(e, SH_EINVAL, "sh_csr_piece_state: NULL argument");
+  if (expected) *expected = A->last_expected;
+  if (round) *round = A->round;
+  for (int c = 0; c < MAX_PIECES; c++) { arrivals[c] = 0xFFFFFFFFu; host_words[c] = A->h_done ? ((volatile uint32_t *)A->h_done)[c] : 0u; }
+  if (!A->d_done)
+    return SH_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t side;
+  HIP_TRY(e, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  // (h_done is 16 words of pinned host memory: the upper 8 receive the counters)
+  if (hipMemcpyAsync(A->h_done + MAX_PIECES, A->d_done, MAX_PIECES * 4, hipMemcpyDeviceToHost, side) == hipSuccess) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ready = false;
+    while (!(ready = hipStreamQuery(side) == hipSuccess) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (ready)
+      for (int c = 0; c < MAX_PIECES; c++) arrivals[c] = ((volatile uint32_t *)A->h_done)[MAX_PIECES + c];
+  }
+  (void)hipStreamDestroy(side);
+  return SH_OK;
 }
 
 int sh_iterate(sh_engine *e, sh_semiring sr, const sh_csr *A, sh_vec *x, const sh_vec *y0,

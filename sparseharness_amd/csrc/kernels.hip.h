@@ -71,9 +71,10 @@ struct StepDev {
   int32_t piece_rows = 0;
   int64_t piece_delta[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t piece_bin_end[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};   // tiled plan: piece c is complete once every row bin below this index is
-  uint32_t *done = nullptr;       // [n_pieces] arrival counters (device memory, never reset), or nullptr: no reporting
-  uint32_t *done_host = nullptr;  // [n_pieces] words in host memory: the `expected`-th, 2*expected-th, ... arrival at done[c] writes its ordinal / expected
+  uint32_t *done = nullptr;       // [n_pieces] arrival counters of THIS launch (device memory; the arrival that completes a piece resets its counter), or nullptr: no reporting
+  uint32_t *done_host = nullptr;  // [n_pieces] words in host memory: the `expected`-th arrival at done[c] writes `round` there
   uint32_t expected = 0;          // arrivals per piece and launch (= workgroups of the reporting launch)
+  uint32_t round = 0;             // this launch's number (sh_spmv_step_pieces counts them per matrix): what a completed piece reports
 };
 __device__ __forceinline__ int64_t row_element(const StepDev &st, int32_t row) {
   return st.n_pieces ? (int64_t)row + st.piece_delta[min(row / st.piece_rows, st.n_pieces - 1)] : (int64_t)row;
@@ -138,11 +139,17 @@ __device__ inline void finish_row_loaded(int32_t row, typename SR::T dot, uint32
 // One workgroup reports "my rows of pieces [c0, c1) are written".  Called by ONE lane after every storing wave of
 // the workgroup has drained its (write-through) row stores and the workgroup has met at a barrier: one arrival per
 // piece; the arrival that completes a launch's round tells the host, which polls done_host[c].
+// The word the host polls carries the launch's OWN round number and the counter starts every launch at zero (the
+// completing arrival resets it; launches on one matrix are ordered by their stream), so launches with different
+// arrival counts -- the tiled plan's workgroups, the single arrival behind the bit-blocked or CSR-stream kernels --
+// can alternate on one matrix without the word running ahead of the rounds.
 __device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
   for (int c = c0; c < c1; c++) {
     const uint32_t n = __hip_atomic_fetch_add(st.done + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (n % st.expected == 0u)
-      __hip_atomic_store(st.done_host + c, n / st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n == st.expected) {
+      __hip_atomic_store(st.done + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(st.done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -151,10 +158,8 @@ __device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
 static __global__ void report_all_pieces(StepDev st) {
   // (launched behind the kernels that wrote the rows: a kernel boundary, their write-through stores are complete)
   if (threadIdx.x == 0 && blockIdx.x == 0)
-    for (int c = 0; c < st.n_pieces; c++) {
-      const uint32_t n = __hip_atomic_fetch_add(st.done + c, st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + st.expected;
-      __hip_atomic_store(st.done_host + c, n / st.expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    for (int c = 0; c < st.n_pieces; c++)
+      __hip_atomic_store(st.done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 

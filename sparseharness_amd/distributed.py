@@ -48,10 +48,14 @@ class ShardPlan:
     """What one rank needs: its rows of the matrix (columns remapped to layout positions) and how they are cut
     into `chunks` pieces of the vector layout."""
 
-    def __init__(self, row_ptr, col_idx, val, rank, world, chunks=1):
+    def __init__(self, row_ptr, col_idx, val, rank, world, chunks=1, semiring=None):
         self.rank, self.world = rank, world
         self.rows_total = len(row_ptr) - 1
-        self.bounds = partition.row_bounds(row_ptr, world, cols=self.rows_total)
+        # Ranges of equal estimated work under the plan a rank's shard runs on: the engine's own weights for the x-tiled /
+        # CSR-stream plans; equal entries when the shards go up in the bit-blocked (or,and) layout (HipLocalStep below:
+        # semiring known, >= 2^22 entries per shard) -- 4 B per entry there, no heavy / light split.
+        bits_shards = semiring == OR_AND_I32 and int(row_ptr[-1]) // max(world, 1) >= 1 << 22
+        self.bounds = partition.row_bounds(row_ptr, world, cols=None if bits_shards else self.rows_total)
         self.layout = partition.SlottedLayout(self.bounds, chunks)
         self.chunks = self.layout.chunks
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
@@ -132,23 +136,48 @@ class HipLocalStep:
         self.round = rnd.value
         self.words = np.ctypeslib.as_array(words, (self.MAX_PIECES,))
 
+    def piece_state(self):
+        """What the engine knows about the reports of the latest launch (sh_csr_piece_state): for the error message of a
+        wait that timed out."""
+        C = self.C
+        arr, words = (C.c_uint32 * self.MAX_PIECES)(), (C.c_uint32 * self.MAX_PIECES)()
+        exp, rnd = C.c_uint32(), C.c_uint32()
+        rc = self.abi.load().sh_csr_piece_state(self.engine.h, self.A.h, arr, words, C.byref(exp), C.byref(rnd))
+        n = self.plan.chunks
+        return {"rc": rc, "round": rnd.value, "expected_arrivals": exp.value, "host_words": list(words)[:n],
+                "device_arrivals": list(arr)[:n], "layout": self.A.describe()}
+
     def wait_piece(self, c, timeout_s=30.0):
-        """Host-side wait until piece c of the launch in flight is written and visible system-wide."""
+        """Host-side wait until piece c of the launch in flight is written and visible system-wide.  The word carries the
+        round number of the launch that completed the piece (rounds only grow)."""
         if self.round is None:
             return
         import time
         t0 = time.perf_counter()
         while self.words[c] < self.round:   # (a word in host memory the reporting launch writes)
             if time.perf_counter() - t0 > timeout_s:
-                raise TimeoutError(f"piece {c} of round {self.round} was not reported within {timeout_s} s")
+                raise TimeoutError(f"rank {self.plan.rank}: piece {c} of round {self.round} was not reported within "
+                                   f"{timeout_s} s: {self.piece_state()}")
 
 
 class ShardedIteration:
     """The do/while of the iterative apps over `world` ranks (torch.distributed must be initialised
     when world > 1).  Tensors live wherever `local.device` says (cuda for HIP, cpu for the tests)."""
 
-    def __init__(self, plan, semiring, local):
+    def __init__(self, plan, semiring, local, exchange=None):
+        """exchange: how a finished piece reaches the other ranks --
+        "collective" (default): one in-place all_gather_into_tensor per piece (RCCL picks the algorithm);
+        "p2p": the direct fan-out SURVEY.md 5 / 8e names as the fallback should RCCL pick a ring (7 steps of 1/8 of the
+               bytes over ONE link each, ~190 us for 33.5 MB, against ~27 us when all 7 xGMI links of a GPU carry its
+               piece at once): one grouped batch of isend / irecv pairs, every rank sending its piece straight to every
+               peer and receiving theirs in place -- point-to-point transfers RCCL runs concurrently, one per link.
+        SH_EXCHANGE=collective|p2p overrides.  Both are bit-identical by construction (the same bytes land in the same
+        places); which is faster on eight GPUs is the driver's measurement to make."""
+        import os
         self.plan, self.semiring, self.local = plan, semiring, local
+        self.exchange = os.environ.get("SH_EXCHANGE") or exchange or "collective"
+        if self.exchange not in ("collective", "p2p"):
+            raise ValueError(f"exchange must be 'collective' or 'p2p', not {self.exchange!r}")
 
     def run(self, x0, y0, alpha, beta, delta=1e-4, max_iters=10000):
         import time
@@ -175,6 +204,9 @@ class ShardedIteration:
             flags_host = flags_host.pin_memory()
             copied = torch.cuda.Event()
         clears_own_flag = isinstance(self.local, HipLocalStep)
+        # (a process group of ONE rank still runs its collectives: the driver's code path -- side stream, in-place
+        # all-gather beside the running launch -- is then exactly what N ranks execute, with nobody to talk to)
+        exchanging = world > 1 or (dist.is_available() and dist.is_initialized())
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
         iters, converged = 0, False
@@ -189,13 +221,26 @@ class ShardedIteration:
             self.local.launch(x_cur, y_vec, x_next, alpha, beta, delta)
             for c in range(chunks):
                 self.local.wait_piece(c)
-                if world > 1:
+                if exchanging:
                     start, length = lay.region(c)
+                    plen = lay.piece_len(c)
                     region = x_next[start:start + length]
-                    mine = region[k * lay.piece_len(c):(k + 1) * lay.piece_len(c)]
+                    mine = region[k * plen:(k + 1) * plen]
+
+                    def fan_out(buf, my_piece):
+                        """Direct exchange: my piece to every peer, every peer's piece into its place in `buf`."""
+                        ops = []
+                        for j in range(world):
+                            if j != k:
+                                ops.append(dist.P2POp(dist.isend, my_piece, j))
+                                ops.append(dist.P2POp(dist.irecv, buf[j * plen:(j + 1) * plen], j))
+                        return dist.batch_isend_irecv(ops) if ops else []
                     if dev.type == "cpu":
                         mine = mine.clone()   # gloo does not take an input aliasing the output
-                        pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
+                        if self.exchange == "p2p":
+                            pending.extend(fan_out(region, mine))
+                        else:
+                            pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
                     elif dist.get_backend() == "gloo":
                         # rehearsal on one GPU (ranks share the card, gloo has no device all-gather): through the host.
                         # The piece is complete and visible: the side stream copies it out while the launch goes on.
@@ -203,7 +248,12 @@ class ShardedIteration:
                             mine_h = mine.to("cpu", non_blocking=True)
                             side.synchronize()
                             region_h = torch.empty(length, dtype=region.dtype)
-                            dist.all_gather_into_tensor(region_h, mine_h)
+                            if self.exchange == "p2p":
+                                region_h[k * plen:(k + 1) * plen] = mine_h
+                                for w in fan_out(region_h, mine_h):
+                                    w.wait()
+                            else:
+                                dist.all_gather_into_tensor(region_h, mine_h)
                             region.copy_(region_h, non_blocking=True)
                             ev = torch.cuda.Event()
                             ev.record(side)
@@ -212,7 +262,10 @@ class ShardedIteration:
                         # piece c is complete and visible (the host has seen its report): its exchange need not wait for
                         # the launch, which is still computing the later pieces on the main stream
                         with torch.cuda.stream(side):
-                            pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
+                            if self.exchange == "p2p":
+                                pending.extend(fan_out(region, mine))
+                            else:
+                                pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
             for w in pending:
                 w.wait()   # (the main stream waits: collective work or the event behind a staged copy)
             torch.index_select(x_next.view(torch.int32), 0, flag_idx, out=flags_dev)

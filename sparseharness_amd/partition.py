@@ -17,26 +17,42 @@ positions.
 import numpy as np
 
 
-def row_bounds(row_ptr, parts, cols=None):
+def row_bounds(row_ptr, parts, cols=None, shard_nnz=None):
     """Boundaries b[0..parts] of contiguous row ranges of ~equal WORK.
 
-    Without `cols`: equal stored entries per range.  With `cols` (the x length) the rows are weighted by the HBM
-    bytes the engine expects to move for them under the plan it would choose (sh_plan_row_work of the C ABI: an
-    entry of a heavy row -- pre-reduced inside phase 1 of the x-tiled plan -- costs a third of an entry of a light
-    row), so that the engine's layout rules and the sharding cannot drift apart.  A shard full of
-    heavy rows would otherwise finish early while the others still stream."""
-    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    Without `cols`: equal stored entries per range (pure numpy, any offset width: a global matrix with 2^31 entries or
+    more -- exactly the kind one shards, since one engine refuses it -- is cut in int64).  With `cols` (the x length)
+    the rows are weighted by the HBM bytes the engine expects to move for them (sh_plan_row_work of the C ABI: under
+    the x-tiled plan an entry of a heavy row -- pre-reduced inside phase 1 -- costs a third of an entry of a light row;
+    see DESIGN.md 3) under the plan it would choose for a matrix of `shard_nnz` entries -- what ONE rank uploads;
+    default: the total over `parts` -- so that a shard full of heavy rows does not finish early while the others still
+    stream.  The weights describe the x-tiled and CSR-stream plans; a caller whose shards run on another layout (the
+    bit-blocked (or,and) plan: 4 B per live entry, no heavy / light split) passes cols=None."""
+    row_ptr = np.asarray(row_ptr)
     rows = len(row_ptr) - 1
-    if cols is not None:
+    if cols is not None and rows > 0:
         import ctypes as C
 
         from . import abi
-        cum = np.zeros(rows + 1, np.uint64)
-        rc = abi.load().sh_plan_row_work(rows, int(cols), int(row_ptr[-1]), row_ptr.ctypes.data_as(C.c_void_p), None,
-                                         cum.ctypes.data_as(C.c_void_p))
-        if rc:
-            raise RuntimeError(f"sh_plan_row_work failed: {rc}")
-        cum = cum.astype(np.int64)
+        total_nnz = int(row_ptr[-1])
+        per_shard = int(shard_nnz) if shard_nnz is not None else -(-total_nnz // max(parts, 1))
+        cum = np.zeros(rows + 1, np.int64)
+        # sh_plan_row_work takes int32 offsets: hand it blocks of rows whose entries fit, offsets rebased per block
+        r = 0
+        lib = abi.load()
+        while r < rows:
+            hi = int(np.searchsorted(row_ptr, int(row_ptr[r]) + (2 ** 31 - 2), side="right")) - 1
+            hi = min(max(hi, r + 1), rows)
+            if int(row_ptr[hi]) - int(row_ptr[r]) > 2 ** 31 - 2:
+                raise ValueError(f"row {r} alone has more than 2^31 - 2 entries")
+            blk = np.ascontiguousarray(row_ptr[r:hi + 1].astype(np.int64) - int(row_ptr[r]), dtype=np.int32)
+            part = np.zeros(hi - r + 1, np.uint64)
+            rc = lib.sh_plan_row_work(hi - r, int(cols), per_shard, blk.ctypes.data_as(C.c_void_p), None,
+                                      part.ctypes.data_as(C.c_void_p))
+            if rc:
+                raise RuntimeError(f"sh_plan_row_work failed: {rc}")
+            cum[r + 1:hi + 1] = cum[r] + part[1:].astype(np.int64)
+            r = hi
     else:
         cum = row_ptr.astype(np.int64)
     total = int(cum[-1])

@@ -213,6 +213,26 @@ def test_headline_sizes_through_the_harness_boundary(spec, workload, expect_corr
     assert abs(app_ms - bench_ms) <= 0.15 * bench_ms, (app_ms, bench_ms)
 
 
+def test_bfs_app_at_config4_size_on_the_layout_it_picks_itself():
+    """bfs_harness -m synth:rmat:23: BASELINE config 4's graph through the C++ mirror of app/bfs.cpp:94-174.  For a
+    matrix of this size the harness uploads the bit-blocked (or,and) layout alone (harness.h) -- 32 row ranges x 16
+    column blocks: the default product path for BFS at this size, which the driver-run suite used to see only up to
+    700 K rows.  Iteration count and the number of reached vertices against the oracle loop."""
+    from oracle import oracle as O
+    from sparseharness_amd import hostlib as H
+    rp, ci, va = H.rmat(23)
+    n = 1 << 23
+    x0 = O.initial_vector(O.OR_AND_I32, n)
+    want, w_it, w_conv = O.iterate(O.OR_AND_I32, rp, ci, va.astype(np.int32), x0, x0, 1, 0, 1e-4, 200)
+    cmd = [os.path.join(HOST, "bin", "bfs_harness"), "-m", "synth:rmat:23", "-f", "rmat-23", "-k", os.path.join(KERNELS, "bfs.json"),
+           "-r", os.path.join(KERNELS, "runfile.csv"), "-n", "gpubox", "-e", "config4", "-i", "1", "-t", "1000", "-x", "200"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SH_QUIET_TIMERS="1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("SH_RESULT")][0]
+    assert f"iterations={w_it} converged={int(w_conv)}" in res, res
+    assert res.endswith(f"set={int((want != 0).sum())}"), res
+
+
 @pytest.mark.parametrize("host_loop", ["0", "1"])
 def test_bfs_app_on_the_bit_blocked_layout(matrix_name, host_loop):
     """bfs_harness with the matrix uploaded in the bit-blocked (or,and) layout only (what the harness does by itself for

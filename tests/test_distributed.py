@@ -70,7 +70,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, q, chunks=1):
+def _worker(rank, world, port, case, q, chunks=1, exchange="collective"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -78,18 +78,18 @@ def _worker(rank, world, port, case, q, chunks=1):
         n = len(rp) - 1
         plan = ShardPlan(rp, ci, va, rank, world, chunks)
         x0 = O.initial_vector(sr, n)
-        final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr)).run(x0, initial_y(sr, x0), a, b,
-                                                                                       1e-4, 500)
+        final, iters, conv = ShardedIteration(plan, sr, OracleLocalStep(plan, sr), exchange=exchange).run(
+            x0, initial_y(sr, x0), a, b, 1e-4, 500)
         q.put((rank, final, iters, conv))
     finally:
         dist.destroy_process_group()
 
 
-def run_world(world, case, chunks=1):
+def run_world(world, case, chunks=1, exchange="collective"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, chunks, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -144,6 +144,33 @@ def test_chunked_overlapped_all_gather_matches_single_process(name, world, chunk
     for rank, final, iters, conv in run_world(world, case, chunks):
         assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
         np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,world,chunks", [("rmat11_sssp", 2, 1), ("1138bus_bfs", 3, 3), ("matrix5_scc", 2, 2)])
+def test_direct_fan_out_exchange_matches_single_process(name, world, chunks):
+    """exchange="p2p" (SH_EXCHANGE=p2p): every rank sends its finished piece straight to every peer and receives theirs
+    in place (one grouped batch of isend / irecv per piece) instead of one all-gather -- the fallback SURVEY.md 5 / 8e
+    names should RCCL pick a ring over xGMI.  Same bytes in the same places: bit-identical vectors and launch counts."""
+    case = cases()[name]
+    sr, rp, ci, va, a, b = case
+    x0 = O.initial_vector(sr, len(rp) - 1)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, initial_y(sr, x0), a, b, 1e-4, 500)
+    for rank, final, iters, conv in run_world(world, case, chunks, exchange="p2p"):
+        assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
+        np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("exchange", ["collective", "p2p"])
+def test_process_group_of_one_rank_still_runs_its_collectives(exchange):
+    """A group of ONE rank executes the driver's exchange code (in-place all-gather per piece / an empty fan-out) instead
+    of skipping it: what the GPU test of the nccl branch relies on."""
+    case = cases()["rmat11_bfs"]
+    sr, rp, ci, va, a, b = case
+    x0 = O.initial_vector(sr, len(rp) - 1)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va, x0, x0, a, b, 1e-4, 500)
+    (rank, final, iters, conv), = run_world(1, case, 3, exchange=exchange)
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(final.view(np.uint32), want.view(np.uint32))
 
 
 def test_world1_driver_equals_oracle():

@@ -589,9 +589,21 @@ def test_config4_rmat23_sssp_and_bfs_to_convergence(eng, plan):
         iters, conv, per, total = eng.iterate(sr, A, xv, yv, sc, a, b, 1e-4, 200)
         assert (iters, conv) == (w_it, w_conv) and conv
         np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
+        A.free()
+        if sr == O.OR_AND_I32:
+            # ... and on the layout bfs_harness (harness.h) and HipLocalStep (distributed.py) pick BY THEMSELVES for a
+            # matrix of this size: the bit-blocked plan alone (or_and_bits = 2) -- 32 row ranges x 16 column blocks at
+            # scale 23.  Same vector, same launch count.
+            A = eng.upload_csr(n, n, rp, ci, vals, or_and_bits=2)
+            assert "or_and=bits(" in A.describe() and "only" in A.describe(), A.describe()
+            xv.upload(x0)
+            yv.upload(x0)
+            iters, conv, per, total = eng.iterate(sr, A, xv, yv, sc, a, b, 1e-4, 200)
+            assert (iters, conv) == (w_it, w_conv) and conv
+            np.testing.assert_array_equal(bits(xv.download(dt)), bits(want))
+            A.free()
         for v in (xv, yv, sc):
             v.free()
-        A.free()
 
 
 def test_config3_rmat23_float_spmv_full_size(eng, plan):
@@ -802,24 +814,81 @@ def test_many_launches_with_changing_inputs_midsize(eng, plan):
     A.free()
 
 
-def _two_rank_worker(rank, world, rendezvous, sr, chunks, q):
-    import torch
-    import torch.distributed as dist
-    # (rendezvous through a file: a TCP port picked by the parent could be taken by someone else before rank 0 binds it)
-    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+def _two_rank_worker(rank, world, rendezvous, sr, chunks, q, log_dir, exchange="collective"):
+    """One rank of the two-rank tests.  Whatever goes wrong here reaches the parent: the traceback travels through the
+    queue, stderr goes to a file the parent prints, and the process group has a short timeout, so a rank whose peer died
+    (or whose piece report never came: HipLocalStep.wait_piece raises with the engine's counters) fails by itself instead
+    of sitting in a collective -- round 3's record holds a 240-second stall of this test that named nothing."""
+    import datetime
+    import sys
+    import traceback
+    sys.stderr = open(os.path.join(log_dir, f"rank{rank}.stderr"), "w", buffering=1)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # (the container's hostname need not resolve)
     try:
-        from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
-        rp, ci, va = H.rmat(15, seed=5)
-        n = len(rp) - 1
-        vals = va.astype(O.elem_dtype(sr))
-        a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
-        x0 = O.initial_vector(sr, n)
-        torch.cuda.set_device(0)
-        plan = ShardPlan(rp, ci, vals, rank, world, chunks)
-        final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0)).run(x0, x0, a, b, 1e-4, 60)
-        q.put((rank, final, iters, conv, plan.r0, plan.r1))
+        import torch
+        import torch.distributed as dist
+        # (rendezvous through a file: a TCP port picked by the parent could be taken by someone else before rank 0 binds it)
+        dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=90))
+        try:
+            from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
+            rp, ci, va = H.rmat(15, seed=5)
+            n = len(rp) - 1
+            vals = va.astype(O.elem_dtype(sr))
+            a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+            x0 = O.initial_vector(sr, n)
+            torch.cuda.set_device(0)
+            plan = ShardPlan(rp, ci, vals, rank, world, chunks)
+            final, iters, conv = ShardedIteration(plan, sr, HipLocalStep(plan, sr, 0), exchange=exchange).run(x0, x0, a, b, 1e-4, 60)
+            q.put((rank, final, iters, conv, plan.r0, plan.r1))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:   # noqa: BLE001 -- the parent must see it
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def _run_two_ranks(sr, chunks, exchange="collective"):
+    """Start the two workers and collect their results; an error tuple from either fails the test with the worker's own
+    traceback and both stderr files."""
+    import tempfile
+
+    import torch.multiprocessing as mp
+    tmp = tempfile.mkdtemp(prefix="sh_two_ranks_")
+    rendezvous = os.path.join(tmp, "store")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, rendezvous, sr, chunks, q, tmp, exchange)) for r in range(2)]
+    for p in procs:
+        p.start()
+
+    def stderr_of_workers():
+        out = []
+        for r in range(2):
+            try:
+                out.append(f"--- rank {r} stderr ---\n" + open(os.path.join(tmp, f"rank{r}.stderr")).read()[-4000:])
+            except OSError:
+                pass
+        return "\n".join(out)
+    try:
+        res = []
+        for _ in procs:
+            try:
+                item = q.get(timeout=240)
+            except Exception:   # noqa: BLE001 -- queue.Empty: nobody reported at all
+                pytest.fail("a worker neither finished nor reported an error within 240 s\n" + stderr_of_workers())
+            if isinstance(item[1], str) and item[1] == "error":
+                pytest.fail(f"rank {item[0]} failed:\n{item[2]}\n" + stderr_of_workers())
+            res.append(item)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, stderr_of_workers()
     finally:
-        dist.destroy_process_group()
+        for p in procs:   # (a worker that hangs must not outlive the test: it would hold the GPU and the run's pipes)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=30)
+    return sorted(res, key=lambda t: t[0])
 
 
 @pytest.mark.parametrize("chunks", [1, 3])
@@ -831,35 +900,99 @@ def test_two_ranks_share_the_gpu_with_hip_local_step(sr, chunks, plan):
     convergence, every rank's final vector and launch count bit-identical to the single-process oracle loop."""
     if plan != "tiled":
         pytest.skip("once per run is enough (the engine picks the plan by size)")
-    import tempfile
-
-    import torch.multiprocessing as mp
     rp, ci, va = H.rmat(15, seed=5)
     n = len(rp) - 1
     vals = va.astype(O.elem_dtype(sr))
     a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
     x0 = O.initial_vector(sr, n)
     want, w_it, w_conv = O.iterate(sr, rp, ci, vals, x0, x0, a, b, 1e-4, 60)
-    rendezvous = os.path.join(tempfile.mkdtemp(prefix="sh_two_ranks_"), "store")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, rendezvous, sr, chunks, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    try:
-        res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
-    finally:
-        for p in procs:   # (a worker that hangs must not outlive the test: it would hold the GPU and the run's pipes)
-            if p.is_alive():
-                p.kill()
-                p.join(timeout=30)
+    res = _run_two_ranks(sr, chunks)
     assert res[1][4] > 0 and res[0][5] == res[1][4]          # rank 1 starts where rank 0 ends, past row 0
     for rank, final, iters, conv, _, _ in res:
         assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
         np.testing.assert_array_equal(bits(final), bits(want))
+
+
+def test_two_ranks_exchange_their_pieces_point_to_point(plan):
+    """The same two ranks with exchange="p2p" (SH_EXCHANGE=p2p): every finished piece goes straight to the peer by a
+    grouped isend / irecv pair instead of an all-gather (host-staged here, as the all-gather of the test above: gloo
+    has no device transfers and two ranks cannot share one GPU under RCCL).  Three pieces per rank, SSSP."""
+    if plan != "tiled":
+        pytest.skip("once per run")
+    sr = O.MIN_PLUS_F32
+    rp, ci, va = H.rmat(15, seed=5)
+    x0 = O.initial_vector(sr, len(rp) - 1)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va.astype(np.float32), x0, x0, 0.0, 0.0, 1e-4, 60)
+    for rank, final, iters, conv, _, _ in _run_two_ranks(sr, 3, exchange="p2p"):
+        assert (iters, conv) == (w_it, w_conv), f"rank {rank}"
+        np.testing.assert_array_equal(bits(final), bits(want))
+
+
+def _nccl_world1_worker(rendezvous, sr, chunks, exchange, q, log_dir):
+    import datetime
+    import sys
+    import traceback
+    sys.stderr = open(os.path.join(log_dir, "rank0.stderr"), "w", buffering=1)
+    try:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"file://{rendezvous}", rank=0, world_size=1,
+                                timeout=datetime.timedelta(seconds=120), device_id=torch.device("cuda", 0))
+        try:
+            from sparseharness_amd.distributed import HipLocalStep, ShardedIteration, ShardPlan
+            rp, ci, va = H.rmat(17, seed=9)
+            vals = va.astype(O.elem_dtype(sr))
+            a, b = (0.0, 0.0) if sr == O.MIN_PLUS_F32 else (1, 0)
+            x0 = O.initial_vector(sr, len(rp) - 1)
+            plan = ShardPlan(rp, ci, vals, 0, 1, chunks)
+            step = HipLocalStep(plan, sr, 0)
+            final, iters, conv = ShardedIteration(plan, sr, step, exchange=exchange).run(x0, x0, a, b, 1e-4, 80)
+            q.put((0, final, iters, conv, step.A.describe()))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:   # noqa: BLE001
+        q.put((0, "error", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("chunks,exchange", [(1, "collective"), (4, "collective"), (4, "p2p")])
+def test_nccl_branch_of_the_driver_runs_beside_the_live_launch(chunks, exchange, plan):
+    """The branch of ShardedIteration that runs on real hardware -- backend nccl (= RCCL), in-place
+    all_gather_into_tensor (or the grouped isend / irecv fan-out) of every finished piece on a side stream WHILE the
+    persistent phase 2 of the same iteration is still computing the later pieces -- executed with a real RCCL process
+    group of one rank (the box has one GPU): the collective is a copy to itself, but the stream semantics, the piece
+    reports and the waits are the ones eight ranks execute.  R-MAT-17 SSSP under the x-tiled plan, bit-exact."""
+    if plan != "tiled":
+        pytest.skip("once per run (SH_PLAN=tiled is what gives the persistent phase 2)")
+    import tempfile
+
+    import torch.multiprocessing as mp
+    sr = O.MIN_PLUS_F32
+    rp, ci, va = H.rmat(17, seed=9)
+    x0 = O.initial_vector(sr, len(rp) - 1)
+    want, w_it, w_conv = O.iterate(sr, rp, ci, va.astype(np.float32), x0, x0, 0.0, 0.0, 1e-4, 80)
+    tmp = tempfile.mkdtemp(prefix="sh_nccl1_")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(os.path.join(tmp, "store"), sr, chunks, exchange, q, tmp))
+    p.start()
+    try:
+        try:
+            item = q.get(timeout=300)
+        except Exception:   # noqa: BLE001
+            pytest.fail("the worker neither finished nor reported an error within 300 s\n" + open(os.path.join(tmp, "rank0.stderr")).read()[-4000:])
+        if isinstance(item[1], str) and item[1] == "error":
+            pytest.fail(item[2] + "\n" + open(os.path.join(tmp, "rank0.stderr")).read()[-4000:])
+        p.join(timeout=60)
+    finally:
+        if p.is_alive():
+            p.kill()
+            p.join(timeout=30)
+    _, final, iters, conv, layout = item
+    assert layout.startswith("tiled"), layout
+    assert (iters, conv) == (w_it, w_conv)
+    np.testing.assert_array_equal(bits(final), bits(want))
 
 
 @pytest.mark.parametrize("name", ["powerlaw_int", "rmat15", "ragged"])

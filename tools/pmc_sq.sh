@@ -11,7 +11,7 @@ if not f:
     print("no counters; stderr tail:"); print(open(sys.argv[1] + "/err.log").read()[-1500:]); sys.exit(0)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
-    if "sh::" in r["Kernel_Name"]:
+    if "sh::spmv" in r["Kernel_Name"] or "sh::bits" in r["Kernel_Name"]:   # (the timed kernels, not the upload's layout builders)
         acc[r["Kernel_Name"].split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)

@@ -183,7 +183,12 @@ constexpr int RL_SHORT = SH_RL_SHORT, RL_MID = 256, RL_WAVE = 4096;
 #endif
 constexpr int RL_BATCH = SH_RL_BATCH;          // products of a one-lane row read per LDS round trip
 constexpr int RL_BATCH8 = 4, RL_BATCH64 = 8;   // the same for the lanes of an 8-lane / a 64-lane row
-constexpr int RL_PAD = 8;                      // spare words behind a product array: a one-lane batch starts inside its row and may read up to 7 words past its (and the image's) end; word 0 of them is where phase 2's loaders drop padding products
+// Spare words behind a product array: a batch starts inside its row and reads on past the row's end with immediate
+// offsets from ONE address register (no clamp per read: three instructions per product less) -- up to 7 words for a
+// one-lane row, 8 * (RL_BATCH8 - 1) + 7 for an 8-lane row, 64 * (RL_BATCH64 - 1) + 63 for a 64-lane row -- so the
+// reads of the image's last row may run this far past the image.  Word 0 of them is where phase 2's loaders drop
+// padding products.
+constexpr int RL_PAD = 64 * RL_BATCH64;
 // rp[] entries may carry RP_SKIP: the row is produced elsewhere (heavy rows of the tiled plan)
 // and must be neither written nor tested here.  Offsets stay below 2^30.
 constexpr int32_t RP_SKIP = 1 << 30, RP_MASK = RP_SKIP - 1;
@@ -248,30 +253,61 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   // additions is the stored order, as before.  (prof: SH_STATS builds, cycles of wave 0 in {MID barrier, one-lane
   // pass, 8-lane rows, 64-lane rows}.)
   SH_STAT(const uint64_t pf_r0 = __builtin_amdgcn_s_memtime();)
-  for (int row = tid; row < nr; row += NT) {
-    const int s = rp[row] & RP_MASK, len = (rp[row + 1] & RP_MASK) - s;
-    if (rp[row] & RP_SKIP)
-      continue;
-    if (len <= RL_SHORT) {
-      T acc = SR::identity();
-      for (int j0 = 0; j0 < len; j0 += RL_BATCH) {
-        uint32_t v[RL_BATCH];
+  // Every row once: its offsets, its class, and the one-lane rows summed on the spot -- R1 rows per thread and trip, so
+  // that the offsets of both and then the first batches of both share one LDS round trip each.
+  constexpr int R1 = 1;   // (two rows per thread and trip measured slower, 200.6 vs 194.6 us same box: profiles/r04_phase2_role_profile.log)
+  for (int row0 = tid; row0 < nr; row0 += R1 * NT) {
+    uint32_t a[R1], b[R1];
 #pragma unroll
-        for (int k = 0; k < RL_BATCH; k++)
-          v[k] = prod[s + j0 + k];   // (up to RL_PAD - 1 words past the row: the product arrays carry them)
-#pragma unroll
-        for (int k = 0; k < RL_BATCH; k++)
-          if (j0 + k < len)
-            acc = SR::add(acc, from_bits<T>(v[k]));
-      }
-      emit(row, acc);
-    } else if (len <= RL_MID) {
-      sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
-    } else if (len <= RL_WAVE) {
-      sc.lst64[atomicAdd(&cnt[1], 1)] = (uint16_t)row;
-    } else {
-      sc.lstB[atomicAdd(&cnt[2], 1)] = (uint16_t)row;
+    for (int k = 0; k < R1; k++) {
+      const int row = min(row0 + k * NT, nr);   // (rp[nr] is the last offset: a row past the end comes out empty)
+      a[k] = (uint32_t)rp[row];
+      b[k] = (uint32_t)rp[min(row + 1, nr)];
     }
+    int s[R1], len1[R1];
+    bool one[R1];
+    T acc[R1];
+#pragma unroll
+    for (int k = 0; k < R1; k++) {
+      const int row = row0 + k * NT;
+      const int len = (int)(b[k] & RP_MASK) - (int)(a[k] & RP_MASK);
+      const bool mine = row < nr && !(a[k] & RP_SKIP);
+      s[k] = (int)(a[k] & RP_MASK);
+      one[k] = mine && len <= RL_SHORT;
+      len1[k] = one[k] ? len : 0;
+      acc[k] = SR::identity();
+      if (mine && len > RL_SHORT) {
+        if (len <= RL_MID) sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
+        else if (len <= RL_WAVE) sc.lst64[atomicAdd(&cnt[1], 1)] = (uint16_t)row;
+        else sc.lstB[atomicAdd(&cnt[2], 1)] = (uint16_t)row;
+      }
+    }
+    for (int j0 = 0; j0 < RL_SHORT; j0 += RL_BATCH) {
+      bool more = false;
+#pragma unroll
+      for (int k = 0; k < R1; k++) more = more || j0 < len1[k];
+      if (!more) break;
+      uint32_t v[R1][RL_BATCH];
+#pragma unroll
+      for (int k = 0; k < R1; k++)
+        if (j0 < len1[k]) {
+#pragma unroll
+          for (int i = 0; i < RL_BATCH; i++)
+            v[k][i] = prod[s[k] + j0 + i];   // (unclamped, immediate offsets from one address: see RL_PAD)
+        }
+#pragma unroll
+      for (int k = 0; k < R1; k++)
+        if (j0 < len1[k]) {
+#pragma unroll
+          for (int i = 0; i < RL_BATCH; i++)
+            if (j0 + i < len1[k])
+              acc[k] = SR::add(acc[k], from_bits<T>(v[k][i]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R1; k++)
+      if (one[k])
+        emit(row0 + k * NT, acc[k]);
   }
   SH_STAT(const uint64_t pf_m0 = __builtin_amdgcn_s_memtime(); if (prof) prof[1] += pf_m0 - pf_r0;)
   lds_barrier();
@@ -285,7 +321,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       uint32_t v[RL_BATCH8];
 #pragma unroll
       for (int k = 0; k < RL_BATCH8; k++)
-        v[k] = prod[min(j + 8 * k, e - 1)];   // (clamped into the row: j < e)
+        v[k] = prod[j + 8 * k];   // (unclamped: see RL_PAD)
 #pragma unroll
       for (int k = 0; k < RL_BATCH8; k++)
         if (j + 8 * k < e)
@@ -304,7 +340,7 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       uint32_t v[RL_BATCH64];
 #pragma unroll
       for (int k = 0; k < RL_BATCH64; k++)
-        v[k] = prod[min(j + 64 * k, e - 1)];
+        v[k] = prod[j + 64 * k];
 #pragma unroll
       for (int k = 0; k < RL_BATCH64; k++)
         if (j + 64 * k < e)

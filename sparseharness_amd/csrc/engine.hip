@@ -580,8 +580,8 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   // P4 / P5: fill
   if (coded) {
     H.vdict_used = (int)H.vdict.size();
-    H.tcode.assign((size_t)(H.code_bits == 4 ? H.stream_len / 2 : H.stream_len), 0);
-    H.vdict.resize(VDICT, 0u);
+    H.tcode.assign(tcode_bytes(H.code_bits, H.stream_len), 0);
+    H.vdict.resize(dict_words(H.code_bits), 0u);
   }
   else H.tval.assign((size_t)H.stream_len, 0u);
   H.tcol.assign((size_t)H.stream_len, TCOL_IDENTITY);   // padding: the identity column, value word / code 0, no fold flag
@@ -596,6 +596,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
     if (coded) {
       const uint32_t code = dict.code[dict.find(val[j])];
       if (H.code_bits == 4) H.tcode[(size_t)pos >> 1] |= (uint8_t)(code << ((pos & 1) * 4));   // both nibbles of a byte belong to one group, one thread
+      else if (H.code_bits == 16) reinterpret_cast<uint16_t *>(H.tcode.data())[(size_t)pos] = (uint16_t)code;
       else H.tcode[(size_t)pos] = (uint8_t)code;
     }
     else H.tval[(size_t)pos] = val[j];
@@ -835,7 +836,7 @@ static void tune_placement(sh_engine *e, sh_csr *m, int tries) {
       {(void **)&m->d_P, (size_t)std::max<int64_t>(m->p_len, 4) * 4 + 16, false},   // (rewritten by every launch)
       {(void **)&m->d_tcol, (size_t)m->stream_len * 2 + SLACK_WIDE, true},
       {coded ? (void **)&m->d_tcode : (void **)&m->d_tval,
-       coded ? (size_t)(m->code_bits == 4 ? m->stream_len / 2 : m->stream_len) + SLACK_TCODE : (size_t)m->stream_len * 4 + SLACK_WIDE, true},
+       coded ? tcode_bytes(m->code_bits, m->stream_len) + SLACK_TCODE : (size_t)m->stream_len * 4 + SLACK_WIDE, true},
       {(void **)&m->d_pslot, (size_t)m->p_len * 2 + SLACK_WIDE, true}};
   const float one = 1.0f, zero = 0.0f;
   auto time_it = [&]() -> float {   // one warm-up, then four launch pairs back to back as one interval (the steady state of a loop)
@@ -1456,7 +1457,11 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       // tiles whose x words are all absorbing are not streamed (semiring.hip.h); (min,+) needs every |value| < 2^103
       const int32_t skip_dead = SR::id == 1 ? (A->skip_minplus ? 1 : 0) : 1;
       if (A->n_chunks > 0) {
-        if (A->n_vdict && A->code_bits == 4)
+        if (A->n_vdict && A->code_bits == 16)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 3>), grid, block, 0, e->stream,
+                             ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
+        else if (A->n_vdict && A->code_bits == 4)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
                              (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
@@ -1785,6 +1790,7 @@ int emulate(const TiledHost &H, int64_t rows, int64_t cols, const uint32_t *x, u
   auto value_at = [&](int64_t q) -> uint32_t {
     if (!coded) return H.tval[(size_t)q];
     if (H.code_bits == 4) return H.vdict[(H.tcode[(size_t)q >> 1] >> ((q & 1) * 4)) & 0xFu];
+    if (H.code_bits == 16) return H.vdict[reinterpret_cast<const uint16_t *>(H.tcode.data())[(size_t)q]];
     return H.vdict[H.tcode[(size_t)q]];
   };
   // ---- phase 1
@@ -2079,7 +2085,7 @@ extern "C" int sh_debug_move_array(sh_engine *e, sh_csr *m, int which, int hold,
   switch (which) {
     case 0: slot = (void **)&m->d_P; bytes = (size_t)std::max<int64_t>(m->p_len, 4) * 4 + 16; break;
     case 1: slot = (void **)&m->d_tcol; bytes = (size_t)m->stream_len * 2 + 16; break;
-    case 2: if (coded) { slot = (void **)&m->d_tcode; bytes = (size_t)(m->code_bits == 4 ? m->stream_len / 2 : m->stream_len) + 64; }
+    case 2: if (coded) { slot = (void **)&m->d_tcode; bytes = tcode_bytes(m->code_bits, m->stream_len) + 64; }
             else { slot = (void **)&m->d_tval; bytes = (size_t)m->stream_len * 4 + 16; }
             break;
     case 3: slot = (void **)&m->d_pslot; bytes = (size_t)m->p_len * 2 + 16; break;

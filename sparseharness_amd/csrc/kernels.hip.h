@@ -660,7 +660,8 @@ struct RowBin { int32_t r0, nr, csr0, gb0, n, pstart, pad0, pt0; };
 #define SH_P1_UNROLL_VC 4
 #endif
 constexpr int P1U_VC = SH_P1_UNROLL_VC;
-constexpr int VDICT = 256;
+constexpr int VDICT = 256;      // one-byte (and four-bit) codes
+constexpr int VDICT16 = 4096;   // two-byte codes: the dictionary (16 KiB) sits in LDS beside the x tile (VC = 3)
 
 // Segmented inclusive scan over a wave: lane i ends up with (+) of t over lanes [i - dist, i]
 // (dist = lanes of the same segment to the left).  Hillis-Steele inside each row of 16 lanes
@@ -689,8 +690,10 @@ __device__ __forceinline__ typename SR::T seg_scan_wave(typename SR::T t, const 
   return t;
 }
 
-// VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values)
-// xs: [TCOLS + 4] words of LDS, ds: [VDICT].
+// VC: 0 = raw 4-byte values, 1 = one-byte dictionary codes, 2 = four-bit codes (<= 16 values), 3 = two-byte codes
+// (<= 4096 values: 4 instead of 6 bytes per entry for a matrix with a few hundred or thousand distinct weights, e.g.
+// small integers after the reference's int narrowing, src/sparse_matrix.cpp:107, or 1 / degree weights)
+// xs: [TCOLS + 4] words of LDS, ds: [VDICT] ([VDICT16] for VC = 3).
 SH_STAT(__device__ uint64_t *g_p1_stats;)
 // per workgroup of phase 2 (wave 0 of each role, shader cycles): [0] loader total, [1] loader in vmcnt waits, [2] loader in
 // barriers, [3] bins, [4] reducer total, [5] reducer in barriers, [6] reducer in the reduction proper, [7] bins,
@@ -716,14 +719,16 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   // reading the chunk's entries -- the first iterations of a search from one vertex touch a handful of tiles.
   const bool may_skip = SR::has_absorbing && skip_dead_tiles;
   // the value words of one group of 4 entries: 4 values, 4 one-byte codes, or 4 nibbles
-  using VWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint32_t, uint16_t>::type>::type;
+  using VWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint32_t, typename std::conditional<VC == 2, uint16_t, uint2>::type>::type>::type;
   // xs[TCOLS] holds the identity: a column code of TCOL_IDENTITY (== TCOLS) reads it with no test
   const VWord *__restrict__ tval = reinterpret_cast<const VWord *>(tval_or_code);
   const uint2 *__restrict__ tcol2 = reinterpret_cast<const uint2 *>(tcol);
   const int tid = threadIdx.x;
   const int c0 = ch.tile * TCOLS;
   const uint32_t ident = to_bits<T>(SR::identity());
-  if (VC && tid < VDICT)
+  if constexpr (VC == 3)
+    reinterpret_cast<uint4 *>(ds)[tid] = reinterpret_cast<const uint4 *>(vdict)[tid];   // TBS * 4 == VDICT16 words
+  else if (VC && tid < VDICT)
     ds[tid] = vdict[tid];
   if (tid == 0)
     xs[TCOLS] = ident;
@@ -769,6 +774,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
       v = make_uint4(ds[w & 0xFFu], ds[(w >> 8) & 0xFFu], ds[(w >> 16) & 0xFFu], ds[w >> 24]);
     else if constexpr (VC == 2)
       v = make_uint4(ds[w & 0xFu], ds[(w >> 4) & 0xFu], ds[(w >> 8) & 0xFu], ds[(w >> 12) & 0xFu]);
+    else if constexpr (VC == 3)
+      v = make_uint4(ds[w.x & 0xFFFFu], ds[w.x >> 16], ds[w.y & 0xFFFFu], ds[w.y >> 16]);
     else
       v = w;
     // (bit 15 of a group's first column code is the fold flag)
@@ -870,8 +877,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
   // partial.  Wave boundaries are fixed by the stream position (chunks are cut at multiples of 64 strips
   // from the heavy run's start), so the builder knows every split.  Deterministic, no atomics.
   if (ch.hs <= ch.s) {
-    using SWord = typename std::conditional<VC == 0, uint4, typename std::conditional<VC == 1, uint4, uint2>::type>::type;
-    constexpr int NV = VC == 0 ? 4 : 1;   // SWords of values per strip: 4 x 16 B raw, 16 B of byte codes, 8 B of nibbles
+    using SWord = typename std::conditional<VC == 2, uint2, uint4>::type;
+    constexpr int NV = VC == 0 ? 4 : (VC == 3 ? 2 : 1);   // SWords of values per strip: 4 x 16 B raw, 16 B of byte codes, 8 B of nibbles, 2 x 16 B of two-byte codes
     const SWord *__restrict__ sval = reinterpret_cast<const SWord *>(tval_or_code);
     const uint4 *__restrict__ scol = reinterpret_cast<const uint4 *>(tcol);
     const int s0 = ch.s / HSTRIP, s1 = ch.e / HSTRIP, sbase = ch.pdelta / HSTRIP;   // strips of the chunk; first heavy strip
@@ -898,6 +905,10 @@ __device__ __forceinline__ void tiled_phase1_chunk(
         } else if constexpr (VC == 1) {
           const uint32_t w = (i / 4 == 0) ? vw[0].x : (i / 4 == 1) ? vw[0].y : (i / 4 == 2) ? vw[0].z : vw[0].w;
           v = ds[(w >> (8 * (i % 4))) & 0xFFu];
+        } else if constexpr (VC == 3) {
+          const uint4 q = vw[i / 8];
+          const uint32_t w = (i % 8 / 2 == 0) ? q.x : (i % 8 / 2 == 1) ? q.y : (i % 8 / 2 == 2) ? q.z : q.w;
+          v = ds[(w >> (16 * (i % 2))) & 0xFFFFu];
         } else {
           const uint32_t w = (i / 8 == 0) ? vw[0].x : vw[0].y;
           v = ds[(w >> (4 * (i % 8))) & 0xFu];
@@ -943,7 +954,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
     uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate, int32_t skip_dead_tiles) {
   __shared__ uint32_t xs[TCOLS + 4];
-  __shared__ uint32_t ds[VC ? VDICT : 1];
+  __shared__ uint32_t ds[VC == 3 ? VDICT16 : (VC ? VDICT : 1)];
+  static_assert(TBS * 4 == VDICT16, "one 16-byte load per thread stages the two-byte dictionary");
   const TileChunk ch = chunks[blockIdx.x];
   if (ch.s >= ch.e || (gate != nullptr && *gate == 0))
     return;   // filler that keeps the XCD-aligned chunk order / the iteration loop is over (StepDev::gate)

@@ -53,11 +53,11 @@ template <class F> static void parallel_items(int64_t n, int64_t grain, int thre
 
 // Small open-addressing set of 4-byte value words with first-come codes (value dictionary of the tiled plan).
 struct ValSet {
-  static constexpr uint32_t VH = 2048, VEMPTY = 0xFFFFFFFFu;
+  static constexpr uint32_t VH = 16384, VEMPTY = 0xFFFFFFFFu;   // (up to VDICT16 words at a load factor of 1/4)
   std::vector<uint32_t> key, code, list;
   bool overflow = false;
   ValSet() : key(VH, 0u), code(VH, VEMPTY) {}
-  static uint32_t hash(uint32_t b) { return (b * 2654435761u) >> 21; }   // 11 bits
+  static uint32_t hash(uint32_t b) { return (b * 2654435761u) >> 18; }   // 14 bits
   uint32_t find(uint32_t b) const {   // slot holding b, or the empty slot where it belongs
     uint32_t h = hash(b);
     while (code[h] != VEMPTY && key[h] != b) h = (h + 1) & (VH - 1);
@@ -66,7 +66,7 @@ struct ValSet {
   void add(uint32_t b) {
     const uint32_t h = find(b);
     if (code[h] != VEMPTY) return;
-    if (list.size() == (size_t)VDICT) { overflow = true; return; }
+    if (list.size() == (size_t)VDICT16) { overflow = true; return; }
     key[h] = b; code[h] = (uint32_t)list.size();
     list.push_back(b);
   }
@@ -81,13 +81,19 @@ struct TiledHost {
   std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
   std::vector<uint32_t> vdict;       // empty = raw values
   int vdict_used = 0;
-  int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values)
+  int code_bits = 0;                 // 8: one code per byte of tcode; 4: two per byte (<= 16 values); 16: two bytes per code (<= 4096 values)
   std::vector<uint16_t> tcol, pslot;
   int64_t stream_len = 0, p_len = 0, light_len = 0, heavy_base = 0;   // light_len: light stream entries (padding included); p_len: products in P
   int64_t light_entries = 0;         // light entries of the matrix (no padding)
   int32_t n_partials = 0;
   double tile_fill = 1.0;            // light (bin, tile) pieces / (bins x tiles): ~1 scattered columns, ~0 local columns
 };
+
+// bytes of the code stream / words of the dictionary for a code width
+static inline size_t tcode_bytes(int code_bits, int64_t stream_len) {
+  return (size_t)(code_bits == 4 ? stream_len / 2 : (code_bits == 16 ? stream_len * 2 : stream_len));
+}
+static inline size_t dict_words(int code_bits) { return code_bits == 16 ? (size_t)VDICT16 : (size_t)VDICT; }
 
 // How one (bin, tile) piece with np pairs and ns single entries is laid out: pair blocks of two groups (4 pairs
 // each; columns without a pair take a single in A and a padding entry in B), then the remaining singles four to a
@@ -117,7 +123,8 @@ static inline void lap(const char *) {}
 
 // Value coding of the stream (see kernels.hip.h): `words` = the distinct 4-byte value words of the matrix (any order;
 // sorted here so that the dictionary does not depend on who found them), `overflow` = there are more than VDICT.
-// <= VDICT distinct bit patterns => the stream carries one-byte codes, <= 16 => four-bit codes.  Code 0 is the all-zero
+// <= VDICT distinct bit patterns => the stream carries one-byte codes, <= 16 => four-bit codes, <= VDICT16 => two-byte
+// codes (value_coding 8 or 4 as an upper limit of the code width rules the wider ones out).  Code 0 is the all-zero
 // word (padding) unless exactly 16 finite non-zero values fill the four-bit table, in which case padding borrows code
 // 0's value: its products are identity (x) finite == identity.  value_coding < 0 keeps raw values (the caller does not
 // get here), 8 never packs nibbles.  On return dict.overflow says "raw values"; else code_bits is 4 or 8 and dict.list the table.
@@ -128,7 +135,7 @@ static inline void decide_value_coding(std::vector<uint32_t> &words, bool overfl
   bool all_finite = true;   // as floats: padding may then carry ANY code (identity (x) finite == identity in all four semirings)
   for (uint32_t b : words) all_finite = all_finite && ((b >> 23) & 0xFFu) != 0xFFu;
   dict = ValSet();
-  if (overflow || words.size() > (size_t)VDICT) {
+  if (overflow || words.size() > (size_t)VDICT16) {
     dict.overflow = true;
   } else if (!bytes_only && words.size() + (has_zero ? 0 : 1) <= 16) {
     code_bits = 4;
@@ -139,6 +146,10 @@ static inline void decide_value_coding(std::vector<uint32_t> &words, bool overfl
     for (uint32_t b : words) dict.add(b);
   } else if (words.size() + (has_zero ? 0 : 1) <= (size_t)VDICT) {
     code_bits = 8;
+    dict.add(0u);
+    for (uint32_t b : words) dict.add(b);
+  } else if (!bytes_only && words.size() + (has_zero ? 0 : 1) <= (size_t)VDICT16) {
+    code_bits = 16;
     dict.add(0u);
     for (uint32_t b : words) dict.add(b);
   } else {

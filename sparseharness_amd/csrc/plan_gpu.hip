@@ -212,8 +212,9 @@ __global__ void k_piece_off(const uint32_t *__restrict__ pB, const uint64_t *__r
 }
 
 // value word -> dictionary code (n_words sorted words in w[], their codes in c[]); raw values: n_words == 0
-struct Coding { const uint32_t *words; const uint8_t *codes; int n_words; };
-__device__ __forceinline__ uint8_t code_of(const uint32_t *w, const uint8_t *c, int n, uint32_t v) {
+// (bits: 4 / 8 -> one byte per entry in code8[], nibbles packed afterwards; 16 -> two bytes per entry)
+struct Coding { const uint32_t *words; const uint16_t *codes; int n_words; int bits; };
+__device__ __forceinline__ uint16_t code_of(const uint32_t *w, const uint16_t *c, int n, uint32_t v) {
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -229,9 +230,14 @@ __global__ void k_fill_light(int64_t L, const uint32_t *__restrict__ iB, const u
                              const int32_t *__restrict__ ci, const uint32_t *__restrict__ val, const RowBin *__restrict__ bins, int64_t cols,
                              Coding cd, uint16_t *__restrict__ tcol, uint8_t *__restrict__ code8, uint32_t *__restrict__ tval,
                              uint16_t *__restrict__ pslot) {
-  __shared__ uint32_t sw[VDICT];
-  __shared__ uint8_t sc[VDICT];
-  for (int k = threadIdx.x; k < cd.n_words; k += PBS) { sw[k] = cd.words[k]; sc[k] = cd.codes[k]; }
+  // a dictionary of up to VDICT words is staged in LDS; a larger one (two-byte codes) is searched where it lies (16 KB: cache hits)
+  __shared__ uint32_t sw_l[VDICT];
+  __shared__ uint16_t sc_l[VDICT];
+  const bool dict_in_lds = cd.n_words <= VDICT;
+  if (dict_in_lds)
+    for (int k = threadIdx.x; k < cd.n_words; k += PBS) { sw_l[k] = cd.words[k]; sc_l[k] = cd.codes[k]; }
+  const uint32_t *sw = dict_in_lds ? sw_l : cd.words;
+  const uint16_t *sc = dict_in_lds ? sc_l : cd.codes;
   __syncthreads();
   const int64_t u = GID;
   if (u >= L) return;
@@ -268,7 +274,11 @@ __global__ void k_fill_light(int64_t L, const uint32_t *__restrict__ iB, const u
   uint16_t tc = ((uint32_t)col < (uint32_t)cols) ? (uint16_t)(col % TCOLS) : TCOL_IDENTITY;
   if (fold_flag) tc |= TCOL_FOLD;
   tcol[q] = tc;
-  if (cd.n_words) code8[q] = code_of(sw, sc, cd.n_words, val[j]);
+  if (cd.n_words) {
+    const uint16_t code = code_of(sw, sc, cd.n_words, val[j]);
+    if (cd.bits == 16) reinterpret_cast<uint16_t *>(code8)[q] = code;
+    else code8[q] = (uint8_t)code;
+  }
   else tval[q] = val[j];
   if (role != ROLE_SECOND) {
     // slot of the product in its bin's image: row-major product order (a run's pairs, then its single) -- except that
@@ -394,9 +404,14 @@ __global__ void k_fill_heavy(int64_t n, const uint8_t *__restrict__ role, const 
                              const uint64_t *__restrict__ c_glob, int64_t heavy_base, const uint32_t *__restrict__ jA,
                              const int32_t *__restrict__ ci, const uint32_t *__restrict__ val, int64_t cols, Coding cd,
                              uint16_t *__restrict__ tcol, uint8_t *__restrict__ code8, uint32_t *__restrict__ tval) {
-  __shared__ uint32_t sw[VDICT];
-  __shared__ uint8_t sc[VDICT];
-  for (int k = threadIdx.x; k < cd.n_words; k += PBS) { sw[k] = cd.words[k]; sc[k] = cd.codes[k]; }
+  // a dictionary of up to VDICT words is staged in LDS; a larger one (two-byte codes) is searched where it lies (16 KB: cache hits)
+  __shared__ uint32_t sw_l[VDICT];
+  __shared__ uint16_t sc_l[VDICT];
+  const bool dict_in_lds = cd.n_words <= VDICT;
+  if (dict_in_lds)
+    for (int k = threadIdx.x; k < cd.n_words; k += PBS) { sw_l[k] = cd.words[k]; sc_l[k] = cd.codes[k]; }
+  const uint32_t *sw = dict_in_lds ? sw_l : cd.words;
+  const uint16_t *sc = dict_in_lds ? sc_l : cd.codes;
   __syncthreads();
   const int64_t i = GID;
   if (i >= n || role[i] != ROLE_HEAVY) return;
@@ -405,7 +420,11 @@ __global__ void k_fill_heavy(int64_t n, const uint8_t *__restrict__ role, const 
   const uint32_t j = jA[i];
   const int32_t col = ci[j];
   tcol[q] = ((uint32_t)col < (uint32_t)cols) ? (uint16_t)(col % TCOLS) : TCOL_IDENTITY;
-  if (cd.n_words) code8[q] = code_of(sw, sc, cd.n_words, val[j]);
+  if (cd.n_words) {
+    const uint16_t code = code_of(sw, sc, cd.n_words, val[j]);
+    if (cd.bits == 16) reinterpret_cast<uint16_t *>(code8)[q] = code;
+    else code8[q] = (uint8_t)code;
+  }
   else tval[q] = val[j];
 }
 __global__ void k_pack_nibbles(const uint8_t *__restrict__ code8, int64_t nbytes, uint8_t *__restrict__ tcode) {
@@ -450,6 +469,28 @@ __global__ void k_distinct(const uint32_t *__restrict__ val, int64_t n, unsigned
       if (old == e) break;
       if (old == 0ull) { if (atomicAdd(&ctl[0], 1u) >= (uint32_t)VDICT) ctl[1] = 1u; break; }
       h = (h + 1) & (DT - 1);
+    }
+  }
+}
+
+// The same for up to VDICT16 words, straight into a table of DT16 slots in device memory (launched only when the table
+// above overflowed: a matrix with a few hundred or thousand distinct values hits existing entries almost always, and one
+// with more overflows within the first blocks; later blocks return at once).
+constexpr int DT16 = 16384;
+__global__ void k_distinct16(const uint32_t *__restrict__ val, int64_t n, unsigned long long *__restrict__ table, uint32_t *__restrict__ ctl) {
+  constexpr int PER = 64;
+  const int64_t base = (int64_t)blockIdx.x * PBS * PER;
+  for (int k = 0; k < PER; k++) {
+    const int64_t i = base + (int64_t)k * PBS + threadIdx.x;
+    if (i >= n || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const unsigned long long e = (1ull << 32) | val[i];
+    uint32_t h = dhash(val[i]) & (DT16 - 1);
+    for (int probes = 0; probes < DT16; probes++) {
+      unsigned long long old = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == 0ull) old = atomicCAS(&table[h], 0ull, e);
+      if (old == e) break;
+      if (old == 0ull) { if (atomicAdd(&ctl[0], 1u) >= (uint32_t)VDICT16) ctl[1] = 1u; break; }
+      h = (h + 1) & (DT16 - 1);
     }
   }
 }
@@ -581,8 +622,8 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   LongRow *d_hv = nullptr;
   unsigned long long *dtable = nullptr;
   uint32_t *dctl = nullptr, *d_words = nullptr;
-  uint8_t *d_codes = nullptr;
-  Coding cd{nullptr, nullptr, 0};
+  uint16_t *d_codes = nullptr;
+  Coding cd{nullptr, nullptr, 0, 0};
   ValSet dict;
   bool coded = false;
   uint32_t u32tmp = 0;
@@ -838,9 +879,22 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     GT(hipMemcpyAsync(ctl, dctl, 16, hipMemcpyDeviceToHost, stream));
     GT(hipStreamSynchronize(stream));
     std::vector<uint32_t> words;
-    const bool overflow = ctl[1] != 0u || ctl[0] > (uint32_t)VDICT;
+    bool overflow = ctl[1] != 0u || ctl[0] > (uint32_t)VDICT;
     if (!overflow)
       for (unsigned long long e : tab) if (e) words.push_back((uint32_t)e);
+    if (overflow && opt.value_coding == 0) {   // more than VDICT words: up to VDICT16 of them still make two-byte codes
+      unsigned long long *dtable16 = pool.get<unsigned long long>((size_t)DT16, true);
+      uint32_t *dctl16 = pool.get<uint32_t>(4, true);
+      POOL_OK();
+      hipLaunchKernelGGL(k_distinct16, dim3((unsigned)((n + (int64_t)PBS * 64 - 1) / ((int64_t)PBS * 64))), dim3(PBS), 0, stream, d_val, n, dtable16, dctl16);
+      std::vector<unsigned long long> tab16((size_t)DT16);
+      GT(hipMemcpyAsync(tab16.data(), dtable16, (size_t)DT16 * 8, hipMemcpyDeviceToHost, stream));
+      GT(hipMemcpyAsync(ctl, dctl16, 16, hipMemcpyDeviceToHost, stream));
+      GT(hipStreamSynchronize(stream));
+      overflow = ctl[1] != 0u || ctl[0] > (uint32_t)VDICT16;
+      if (!overflow)
+        for (unsigned long long e : tab16) if (e) words.push_back((uint32_t)e);
+    }
     decide_value_coding(words, overflow, opt, H.code_bits, dict);
     coded = !dict.overflow;
   }
@@ -848,18 +902,18 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     H.vdict = dict.list;
     H.vdict_used = (int)H.vdict.size();
     // sorted words and their codes for the device lookup
-    std::vector<std::pair<uint32_t, uint8_t>> wc;
-    for (size_t k = 0; k < dict.list.size(); k++) wc.emplace_back(dict.list[k], (uint8_t)k);
+    std::vector<std::pair<uint32_t, uint16_t>> wc;
+    for (size_t k = 0; k < dict.list.size(); k++) wc.emplace_back(dict.list[k], (uint16_t)k);
     std::sort(wc.begin(), wc.end());
-    std::vector<uint32_t> ws; std::vector<uint8_t> cs;
+    std::vector<uint32_t> ws; std::vector<uint16_t> cs;
     for (auto &pr : wc) { ws.push_back(pr.first); cs.push_back(pr.second); }
-    d_words = pool.get<uint32_t>(VDICT); d_codes = pool.get<uint8_t>(VDICT);
+    d_words = pool.get<uint32_t>(VDICT16); d_codes = pool.get<uint16_t>(VDICT16);
     POOL_OK();
     GT(hipMemcpyAsync(d_words, ws.data(), ws.size() * 4, hipMemcpyHostToDevice, stream));
-    GT(hipMemcpyAsync(d_codes, cs.data(), cs.size(), hipMemcpyHostToDevice, stream));
+    GT(hipMemcpyAsync(d_codes, cs.data(), cs.size() * 2, hipMemcpyHostToDevice, stream));
     GT(hipStreamSynchronize(stream));
-    cd = Coding{d_words, d_codes, (int)ws.size()};
-    H.vdict.resize(VDICT, 0u);
+    cd = Coding{d_words, d_codes, (int)ws.size(), H.code_bits};
+    H.vdict.resize(dict_words(H.code_bits), 0u);
   }
 
   PHASE("  dictionary");
@@ -877,7 +931,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   GT(hipMalloc((void **)&D.ptab, D.n_ptab * 4 + SLACK_WIDE));
   GT(hipMalloc((void **)&D.obase, D.n_obase * 4 + SLACK_WIDE));
   if (coded) {
-    D.n_tcode = (size_t)(H.code_bits == 4 ? H.stream_len / 2 : H.stream_len);
+    D.n_tcode = tcode_bytes(H.code_bits, H.stream_len);
     GT(hipMalloc((void **)&D.tcode, D.n_tcode + SLACK_TCODE));
     if (H.code_bits == 4) { code8 = pool.get<uint8_t>((size_t)H.stream_len, true); POOL_OK(); }
     else { code8 = D.tcode; GT(hipMemsetAsync(D.tcode, 0, D.n_tcode, stream)); }

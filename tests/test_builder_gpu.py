@@ -78,6 +78,11 @@ def random_matrix(rng, rows, cols, avg, heavy=0, hlen=3000, oob=False, local=Fal
         va = rng.integers(0, 9, nnz).astype(np.float32)                    # zero among them
     elif values == "bytes":
         va = rng.integers(0, 200, nnz).astype(np.float32)                  # one-byte codes
+    elif values == "words":
+        va = rng.integers(0, 3000, nnz).astype(np.float32)                 # two-byte codes (value_coding = 8 in OPTIONS: raw)
+    elif values == "words_full":
+        va = (1 + rng.integers(0, 4095, nnz)).astype(np.float32)           # 4095 values + the padding word: the table is full
+        va[:4095] = 1 + np.arange(4095)
     else:
         va = rng.random(nnz).astype(np.float32)                            # raw
     return rp, ci, va
@@ -87,7 +92,7 @@ SHAPES = [  # rows, cols, avg degree, heavy rows, extra
     (3000, 3000, 8, 2, {}), (3000, 100_000, 12, 3, {}), (20_000, 200_000, 10, 4, {}), (500, 70_000, 40, 5, dict(hlen=9000)),
     (3000, 100_000, 12, 3, dict(oob=True)), (8000, 40_000, 15, 0, dict(local=True)), (100, 33_000, 3, 0, {}), (1, 5, 3, 0, {}),
     (40_000, 1_000_000, 14, 6, dict(hlen=20_000)), (3000, 100_000, 12, 3, dict(values="few")), (3000, 100_000, 12, 3, dict(values="bytes")),
-    (3000, 100_000, 12, 3, dict(values="real")),
+    (3000, 100_000, 12, 3, dict(values="real")), (3000, 100_000, 12, 3, dict(values="words")), (20_000, 200_000, 10, 4, dict(values="words_full")),
 ]
 OPTIONS = [dict(fold=1), dict(fold=0), dict(fold=1, value_coding=-1), dict(fold=1, value_coding=8), dict(fold=1, chunk=2048), dict(fold=1, heavy_per_tile=2)]
 

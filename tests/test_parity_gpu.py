@@ -814,6 +814,45 @@ def test_many_launches_with_changing_inputs_midsize(eng, plan):
     A.free()
 
 
+@pytest.mark.parametrize("distinct", [257, 1000, 4095])
+def test_two_byte_value_codes_match_oracle(eng, distinct, plan):
+    """A matrix with more than 256 distinct value words (what the reference's int-narrowed weights, src/sparse_matrix.cpp:107,
+    or 1 / degree weights give): the tiled plan's stream carries two-byte codes into a 4096-word dictionary in LDS
+    (values=dict16, VC = 3 of spmv_tiled_phase1; 4 instead of 6 bytes per entry).  All four semirings, epilogues with y,
+    light groups with folded pairs, heavy strips; bit-exact against the oracle on integer-valued data, both builders."""
+    if plan != "tiled":
+        pytest.skip("value coding belongs to the tiled plan")
+    import os
+    if os.environ.get("SH_VALCODE") != "auto":
+        pytest.skip("needs the default value-coding policy")
+    rng = np.random.default_rng(distinct)
+    rows, cols = 60_000, 200_000
+    deg = rng.poisson(9, rows).astype(np.int64)
+    deg[rng.integers(0, rows, 5)] = 4000          # heavy rows
+    deg[rng.integers(0, rows, 300)] = rng.integers(30, 300, 300)
+    rp = np.zeros(rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, cols, nnz).astype(np.int32)
+    vi = (1 + rng.integers(0, distinct, nnz)).astype(np.int32)
+    vi[:distinct] = 1 + np.arange(distinct)
+    x = rng.integers(0, 4, cols).astype(np.int32)
+    y = rng.integers(-3, 4, rows).astype(np.int32)
+    for build in (1, 2):
+        for sr, vals, xx, yy, a, b in ((O.PLUS_TIMES_F32, vi.astype(np.float32), x.astype(np.float32), y.astype(np.float32), 2.0, 1.0),
+                                       (O.MIN_PLUS_F32, vi.astype(np.float32), x.astype(np.float32), y.astype(np.float32), 0.0, 0.0),
+                                       (O.OR_AND_I32, vi, x, y, 1, 1), (O.MAX_MIN_I32, vi, x, y, O.INT_MAX, O.INT_MIN)):
+            A = eng.upload_csr(rows, cols, rp, ci, vals, build=build)
+            assert f"values=dict16({distinct + 1})" in A.describe(), A.describe()
+            xv, yv, out = eng.vector(xx), eng.vector(yy), eng.alloc(rows).fill(0)
+            eng.spmv(sr, A, xv, yv, a, b, out)
+            want = O.kernel(sr, rp, ci, vals, xx, yy, a, b, vlength=cols)
+            np.testing.assert_array_equal(bits(out.download(vals.dtype)), bits(want))
+            for v in (xv, yv, out):
+                v.free()
+            A.free()
+
+
 def _two_rank_worker(rank, world, rendezvous, sr, chunks, q, log_dir, exchange="collective"):
     """One rank of the two-rank tests.  Whatever goes wrong here reaches the parent: the traceback travels through the
     queue, stderr goes to a file the parent prints, and the process group has a short timeout, so a rank whose peer died

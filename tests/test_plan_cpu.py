@@ -104,6 +104,29 @@ def test_emulated_plan_equals_csr_product(emu, shape):
                 assert st["products"] >= st["light"]                  # one product per light entry (+ padding)
 
 
+@pytest.mark.parametrize("distinct", [300, 4095, 4096, 6000])
+def test_two_byte_value_codes(emu, distinct):
+    """More than 256 distinct value words: up to 4096 (the padding word 0 included) travel as two-byte codes into a
+    dictionary that sits in LDS beside the x tile (VC = 3 of spmv_tiled_phase1); beyond that the stream carries the raw
+    values.  Light groups, folded pairs and heavy strips through either stream, walked on the host."""
+    rng = np.random.default_rng(distinct)
+    rp, ci, va = random_matrix(rng, 6000, 120_000, 12, 3)
+    va = (1 + rng.integers(0, distinct, len(va))).astype(np.float32)
+    va[:distinct] = 1 + np.arange(distinct)          # every value occurs
+    for sem in (0, 2):
+        vals = va if sem == 0 else va.astype(np.int32)
+        for options in (dict(fold=1), dict(fold=0), dict(fold=1, value_coding=8)):
+            rc, y, st, x = emulate(emu, 6000, 120_000, rp, ci, vals, sem, **options)
+            assert rc == 0 and st["poison_reads"] == 0, (rc, options, st)
+            want = exact(6000, 120_000, rp, ci, vals, x, sem)
+            if sem == 0:   # (the three 3000-entry rows sum past 2^24 with values this large: float order matters there)
+                big = np.diff(rp) * distinct * 7 >= 2 ** 24
+                np.testing.assert_array_equal(y[~big], want[~big], err_msg=str((sem, options)))
+                np.testing.assert_allclose(y[big], want[big], rtol=1e-6)
+            else:
+                np.testing.assert_array_equal(y, want, err_msg=str((sem, options)))
+
+
 def test_folding_removes_the_duplicates_of_a_row_inside_a_tile(emu):
     """A matrix whose rows keep their columns within one tile: with folding a row of d entries travels through P as
     ceil(d / 2) products (+ padding), without as d."""

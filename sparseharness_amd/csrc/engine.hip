@@ -61,6 +61,10 @@ struct sh_csr {
   int32_t n_chunks = 0;
   uint32_t *d_tval = nullptr, *d_gdest = nullptr, *d_gblk = nullptr, *d_P = nullptr, *d_obase = nullptr;
   int32_t *d_ptab = nullptr;
+  uint16_t *d_ptile = nullptr;     // per piece: its column tile
+  int32_t *d_ptab_live = nullptr;  // per launch of a semiring with absorbing words: ptab with the pieces of dead tiles marked (tiled_mark_dead)
+  uint32_t *d_tile_live = nullptr; // per column tile: phase 1 found a word of x that is not absorbing
+  int64_t n_pieces = 0;
   uint8_t *d_tcode = nullptr;    // value coding: one-byte dictionary codes instead of d_tval
   uint32_t *d_vdict = nullptr;   // [VDICT] original bit patterns
   int n_vdict = 0;               // 0 = values stored raw
@@ -86,6 +90,9 @@ struct sh_csr {
   size_t bits_bytes = 0;
   bool bits_only = false;                     // no other plan was built: only SH_OR_AND_I32 launches are served
   uint32_t *d_done = nullptr, *h_done = nullptr;   // piece reporting (sh_spmv_step_pieces): arrival counters / host-visible round words
+  PieceDev *d_pcs = nullptr;                  // the pieces' geometry as the kernels read it (device copy of pcs_host)
+  PieceDev pcs_host{};                        // what d_pcs holds (rewritten only when a call brings another geometry)
+  bool pcs_valid = false;
   uint32_t round = 0;                         // reporting launches so far
   uint32_t last_expected = 0;                 // arrivals per piece the latest reporting launch waits for (sh_csr_piece_state)
   bool built_on_device = false;               // the tiled layout was built by plan_gpu.hip
@@ -589,6 +596,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
   H.pslot.assign((size_t)H.p_len, TSLOT_PAD);
   H.gblk.assign((size_t)(n_blocks_total + 1) * 4, 0u);
   H.ptab.assign((size_t)n_pieces_total + 1, 0);
+  H.ptile.assign((size_t)n_pieces_total + 1, 0);
   std::atomic<bool> ok{true};
   auto put_entry = [&](int64_t pos, int32_t j) {
     const int32_t c = ci[j];
@@ -617,6 +625,7 @@ static bool build_tiled_plan(int64_t rows, int64_t cols, int64_t nnz, const int3
         // P address is ptab[its piece] + its group index inside the bin.  gblk marks the group that starts a piece.
         const int64_t g_in_bin = (off - b.pstart) / 4;
         H.ptab[(size_t)b.pt0 + (size_t)piece_k] = (int32_t)(ppos / 4 - g_in_bin);
+        H.ptile[(size_t)b.pt0 + (size_t)piece_k] = (uint16_t)pc.tile;
         uint32_t *rec = &H.gblk[((size_t)b.gb0 + (size_t)(g_in_bin / 64)) * 4];
         rec[(g_in_bin % 64) / 32] |= 1u << (g_in_bin % 32);
       }
@@ -800,7 +809,7 @@ static void autotune_plan(sh_engine *e, sh_csr *m) {
     m->tiled_bytes = 0;
     for (void **p : {(void **)&m->d_bins, (void **)&m->d_chunks, (void **)&m->d_tval, (void **)&m->d_tcol, (void **)&m->d_gdest,
                      (void **)&m->d_pslot, (void **)&m->d_gblk, (void **)&m->d_ptab, (void **)&m->d_P, (void **)&m->d_tlong, (void **)&m->d_tpartial,
-                     (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_obase}) {
+                     (void **)&m->d_ptile, (void **)&m->d_ptab_live, (void **)&m->d_tile_live, (void **)&m->d_lrp, (void **)&m->d_tcode, (void **)&m->d_vdict, (void **)&m->d_obase}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -1167,6 +1176,15 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     td_n = td.n_gdest; PLAN_ARRAY(m->d_gdest, td.gdest, th.gdest, 4, SLACK_WIDE);
     td_n = td.n_gblk; PLAN_ARRAY(m->d_gblk, td.gblk, th.gblk, 4, SLACK_WIDE);
     td_n = td.n_ptab; PLAN_ARRAY(m->d_ptab, td.ptab, th.ptab, 4, SLACK_WIDE);
+    td_n = td.n_ptab; PLAN_ARRAY(m->d_ptile, td.ptile, th.ptile, 2, SLACK_WIDE);
+    m->n_pieces = (int64_t)(m->built_on_device ? td.n_ptab : th.ptab.size());
+    // dead pieces (launches of a semiring with absorbing words): the marked copy of ptab, the tiles' live words (all live until a launch says otherwise)
+    DEV_ARRAY(m->d_ptab_live, (const int32_t *)nullptr, (size_t)m->n_pieces * 4, SLACK_WIDE);
+    {
+      const size_t ct = (size_t)std::max<int64_t>(1, (m->cols + TCOLS - 1) / TCOLS);
+      DEV_ARRAY(m->d_tile_live, (const uint32_t *)nullptr, ct * 4, 0);
+      HIP_TRY_M(hipMemsetD32Async((hipDeviceptr_t)m->d_tile_live, 1, ct, e->stream));
+    }
     td_n = td.n_pslot; PLAN_ARRAY(m->d_pslot, td.pslot, th.pslot, 2, SLACK_WIDE);
     td_n = td.n_obase; PLAN_ARRAY(m->d_obase, td.obase, th.obase, 4, SLACK_WIDE);
     DEV_ARRAY(m->d_P, (const uint32_t *)nullptr, (size_t)std::max<int64_t>(m->p_len, 4) * 4, 16);
@@ -1212,8 +1230,8 @@ int sh_csr_free(sh_engine *e, sh_csr *m) {
   if (m->d_long) (void)hipFree(m->d_long);
   if (m->d_partial) (void)hipFree(m->d_partial);
   for (void *p : {(void *)m->d_bins, (void *)m->d_chunks, (void *)m->d_tval, (void *)m->d_tcol, (void *)m->d_gdest,
-                  (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
-                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase, (void *)m->d_done, (void *)m->d_bits_items,
+                  (void *)m->d_pslot, (void *)m->d_gblk, (void *)m->d_ptab, (void *)m->d_ptile, (void *)m->d_ptab_live, (void *)m->d_tile_live, (void *)m->d_P, (void *)m->d_tlong, (void *)m->d_tpartial, (void *)m->d_lrp,
+                  (void *)m->d_tcode, (void *)m->d_vdict, (void *)m->d_obase, (void *)m->d_done, (void *)m->d_pcs, (void *)m->d_bits_items,
                   (void *)m->d_bits_ent, (void *)m->d_bits_partial, (void *)m->d_bits_sub, (void *)m->d_bits_rr0, (void *)m->d_xbits})
     if (p) (void)hipFree(p);
   if (m->h_done) (void)hipHostFree(m->h_done);
@@ -1432,7 +1450,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                            (uint32_t *)out->d, st);
         HIP_TRY(e, hipGetLastError());
       }
-      if (st.done) {
+      if (st.expected) {
         hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
         HIP_TRY(e, hipGetLastError());
       }
@@ -1451,36 +1469,48 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_p1_stats), &p1_stats, sizeof p1_stats, 0, hipMemcpyHostToDevice, e->stream);
     }
 #endif
+    bool mark_dead = false;
     {
       const TileChunk *ch = A->d_chunks;
       const dim3 grid((unsigned)A->n_chunks), block(TBS);
       // tiles whose x words are all absorbing are not streamed (semiring.hip.h); (min,+) needs every |value| < 2^103
       const int32_t skip_dead = SR::id == 1 ? (A->skip_minplus ? 1 : 0) : 1;
+      // ... and their products are neither written by phase 1 nor read by phase 2: phase 1 leaves a live word per tile,
+      // tiled_mark_dead turns it into a copy of the piece table whose dead pieces point at one group of identity
+      // words, phase 2 reads the pieces through that copy (semirings with absorbing words only)
+      mark_dead = SR::has_absorbing && skip_dead && A->n_bins > 0 && A->n_pieces > 0;
+      uint32_t *tile_live = mark_dead ? A->d_tile_live : nullptr;
       if (A->n_chunks > 0) {
         if (A->n_vdict && A->code_bits == 16)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 3>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead, tile_live);
         else if (A->n_vdict && A->code_bits == 4)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 2>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead, tile_live);
         else if (A->n_vdict)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 1>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tcode, A->d_vdict, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead, tile_live);
         else
           hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase1<SR, 0>), grid, block, 0, e->stream,
                              ch, (const void *)A->d_tval, (const uint32_t *)nullptr, A->d_tcol, A->d_gdest, A->d_obase,
-                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead);
+                             (const uint32_t *)x->d, (int32_t)A->cols, A->d_P, A->d_tpartial, st.gate, skip_dead, tile_live);
         HIP_TRY(e, hipGetLastError());
       }
+    }
+    if (mark_dead) {
+      const uint32_t ident = SR::identity_bits;
+      hipLaunchKernelGGL(tiled_mark_dead, dim3((unsigned)((A->n_pieces + 255) / 256)), dim3(256), 0, e->stream, A->d_ptab, A->d_ptile,
+                         (const uint32_t *)A->d_tile_live, A->d_ptab_live, A->n_pieces, A->d_P + std::max<int64_t>(A->p_len, 4), ident, st.gate);
+      HIP_TRY(e, hipGetLastError());
     }
     // phase 2; its reducer waves also add up the heavy rows' partials while the loaders fill the first bin
     if (A->n_bins > 0) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_tiled_phase2s<SR>), dim3(std::min(A->n_bins, e->n_cus)), dim3(P2S_BS), 0,
                          e->stream, A->d_bins, A->n_bins, A->d_lrp, A->d_P, (int32_t)(std::max<int64_t>(A->p_len, 4) / 4 - 1), A->d_pslot,
-                         (const uint4 *)A->d_gblk, A->d_ptab, A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
+                         (const uint4 *)A->d_gblk, mark_dead ? A->d_ptab_live : A->d_ptab, A->d_tlong, A->n_tlong, A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0,
                          (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
@@ -1521,7 +1551,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                          A->d_tpartial, yp, alpha, beta, use_y ? 1 : 0, (uint32_t *)out->d, st);
       HIP_TRY(e, hipGetLastError());
     }
-    if (st.done && A->n_bins == 0) {          // nobody reported: one arrival per piece behind everything
+    if (st.expected && A->n_bins == 0) {      // nobody reported: one arrival per piece behind everything
       hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
       HIP_TRY(e, hipGetLastError());
     }
@@ -1543,7 +1573,7 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                        (uint32_t *)out->d, st);
     HIP_TRY(e, hipGetLastError());
   }
-  if (st.done) {   // the CSR-stream kernels do not report pieces: one arrival per piece behind them
+  if (st.expected) {   // the CSR-stream kernels do not report pieces: one arrival per piece behind them
     hipLaunchKernelGGL(report_all_pieces, dim3(1), dim3(64), 0, e->stream, st);
     HIP_TRY(e, hipGetLastError());
   }
@@ -1629,27 +1659,38 @@ int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x
     return fail(e, SH_EINVAL, "sh_spmv_step_pieces: out must not alias x");
   HIP_TRY(e, hipSetDevice(e->device));
   StepDev st{changed_flag_device, (const uint32_t *)x->d, 0, delta};
-  st.n_pieces = pc->n_pieces;
-  st.piece_rows = pc->piece_rows;
+  PieceDev pd{};
+  pd.n_pieces = pc->n_pieces;
+  pd.piece_rows = pc->piece_rows;
   for (int c = 0; c < pc->n_pieces; c++) {
     const int64_t first = (int64_t)c * pc->piece_rows, rows_c = std::max<int64_t>(0, std::min<int64_t>(A->rows - first, pc->piece_rows));
     const int64_t at = pc->element_of_piece[c];
     if (at < 0 || at + rows_c > out->n || at + rows_c > x->n || (y && at + rows_c > y->n))
       return fail(e, SH_ESHAPE, "sh_spmv_step_pieces: piece %d (%lld rows at element %lld) does not fit the vectors", c, (long long)rows_c, (long long)at);
-    st.piece_delta[c] = at - first;
+    pd.piece_delta[c] = at - first;
     // tiled plan: the piece is complete once every bin that starts below its last row + 1 is reduced
-    st.piece_bin_end[c] = (int32_t)(std::lower_bound(A->bin_r0.begin(), A->bin_r0.end(), (int32_t)std::min<int64_t>(first + pc->piece_rows, A->rows)) - A->bin_r0.begin());
+    pd.piece_bin_end[c] = (int32_t)(std::lower_bound(A->bin_r0.begin(), A->bin_r0.end(), (int32_t)std::min<int64_t>(first + pc->piece_rows, A->rows)) - A->bin_r0.begin());
   }
-  if (pc->n_pieces > 0) st.piece_bin_end[pc->n_pieces - 1] = (int32_t)A->bin_r0.size();
+  if (pc->n_pieces > 0) pd.piece_bin_end[pc->n_pieces - 1] = (int32_t)A->bin_r0.size();
+  if (!A->d_done) {
+    HIP_TRY(e, hipMalloc((void **)&A->d_done, MAX_PIECES * 4));
+    HIP_TRY(e, hipMemsetAsync(A->d_done, 0, MAX_PIECES * 4, e->stream));
+    HIP_TRY(e, hipHostMalloc((void **)&A->h_done, 64, hipHostMallocDefault));
+    memset(A->h_done, 0, 64);
+    HIP_TRY(e, hipMalloc((void **)&A->d_pcs, sizeof(PieceDev)));
+  }
+  pd.done = A->d_done;
+  pd.done_host = A->h_done;
+  // the geometry goes to device memory once (an iteration loop brings the same one every time); a changed one is
+  // copied behind the launches already enqueued on this stream, which keep reading the old bytes until then
+  if (!A->pcs_valid || memcmp(&pd, &A->pcs_host, sizeof pd) != 0) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // (pcs_host is the copy's source: it must not change under a copy in flight)
+    A->pcs_host = pd;
+    HIP_TRY(e, hipMemcpyAsync(A->d_pcs, &A->pcs_host, sizeof pd, hipMemcpyHostToDevice, e->stream));
+    A->pcs_valid = true;
+  }
+  st.pcs = A->d_pcs;
   if (pc->report) {
-    if (!A->d_done) {
-      HIP_TRY(e, hipMalloc((void **)&A->d_done, MAX_PIECES * 4));
-      HIP_TRY(e, hipMemsetAsync(A->d_done, 0, MAX_PIECES * 4, e->stream));
-      HIP_TRY(e, hipHostMalloc((void **)&A->h_done, 64, hipHostMallocDefault));
-      memset(A->h_done, 0, 64);
-    }
-    st.done = A->d_done;
-    st.done_host = A->h_done;
     // arrivals per piece and launch: one per workgroup of phase 2, or the single one of report_all_pieces
     st.expected = (A->plan == PLAN_TILED && A->n_bins > 0 && !(sr == SH_OR_AND_I32 && A->d_bits_items)) ? (uint32_t)std::min(A->n_bins, e->n_cus) : 1u;
     A->round++;
@@ -2020,6 +2061,7 @@ extern "C" int sh_debug_compare_builds(sh_engine *e, int64_t rows, int64_t cols,
   dev_bytes("pslot", hh.pslot.data(), hh.pslot.size() * 2, td.pslot, td.n_pslot, 2);
   dev_bytes("gblk", hh.gblk.data(), hh.gblk.size() * 4, td.gblk, td.n_gblk, 4);
   dev_bytes("ptab", hh.ptab.data(), hh.ptab.size() * 4, td.ptab, td.n_ptab, 4);
+  dev_bytes("ptile", hh.ptile.data(), hh.ptile.size() * 2, td.ptile, td.n_ptab, 2);
   dev_bytes("obase", hh.obase.data(), hh.obase.size() * 4, td.obase, td.n_obase, 4);
   if (!hip_ok) { rep += "hipMemcpy (download) failed\n"; return finish(-3); }
   return finish(diffs);

@@ -26,6 +26,7 @@
 //
 // HBM-bound (0.23 flop/B): no MFMA by design.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 #include "semiring.hip.h"
 
@@ -64,20 +65,27 @@ struct StepDev {
   const int32_t *gate = nullptr;
   // Row pieces (multi-GPU iteration driver, sh_spmv_step_pieces): the matrix' rows live in n_pieces runs of piece_rows
   // rows; row r of piece c = r / piece_rows is element r + piece_delta[c] of out, y and prev (the vectors interleave
-  // the pieces of all ranks so that one piece of every rank is one contiguous region to all-gather).  When a
+  // the pieces of all ranks so that one piece of every rank is one contiguous region to all-gather).  The geometry
+  // lives in device memory (PieceDev, one per matrix, rewritten only when it changes), not in the kernel arguments:
+  // as 30 more preloaded SGPRs it made spmv_tiled_phase2s spill scalar registers.  When a
   // workgroup has written its last row of piece c it adds 1 to done[c] (after a release at system scope): the
   // host, polling, then starts the exchange of that piece while the later ones are still being computed.
-  int32_t n_pieces = 0;     // 0: rows are elements 0..rows-1
-  int32_t piece_rows = 0;
-  int64_t piece_delta[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int32_t piece_bin_end[MAX_PIECES] = {0, 0, 0, 0, 0, 0, 0, 0};   // tiled plan: piece c is complete once every row bin below this index is
-  uint32_t *done = nullptr;       // [n_pieces] arrival counters of THIS launch (device memory; the arrival that completes a piece resets its counter), or nullptr: no reporting
-  uint32_t *done_host = nullptr;  // [n_pieces] words in host memory: the `expected`-th arrival at done[c] writes `round` there
-  uint32_t expected = 0;          // arrivals per piece and launch (= workgroups of the reporting launch)
+  const struct PieceDev *pcs = nullptr;   // nullptr: rows are elements 0..rows-1, nothing is reported
+  uint32_t expected = 0;          // arrivals per piece and launch (= workgroups of the reporting launch); 0: no reporting
   uint32_t round = 0;             // this launch's number (sh_spmv_step_pieces counts them per matrix): what a completed piece reports
 };
+struct PieceDev {
+  int32_t n_pieces;
+  int32_t piece_rows;
+  int64_t piece_delta[MAX_PIECES];
+  int32_t piece_bin_end[MAX_PIECES];   // tiled plan: piece c is complete once every row bin below this index is
+  uint32_t *done;                      // [n_pieces] arrival counters of the launch in flight (device memory; the arrival that completes a piece resets its counter)
+  uint32_t *done_host;                 // [n_pieces] words in host memory: the `expected`-th arrival at done[c] writes the launch's round there
+};
+__device__ __forceinline__ bool reports(const StepDev &st) { return st.expected != 0u; }
 __device__ __forceinline__ int64_t row_element(const StepDev &st, int32_t row) {
-  return st.n_pieces ? (int64_t)row + st.piece_delta[min(row / st.piece_rows, st.n_pieces - 1)] : (int64_t)row;
+  const PieceDev *pc = st.pcs;
+  return pc ? (int64_t)row + pc->piece_delta[min(row / pc->piece_rows, pc->n_pieces - 1)] : (int64_t)row;
 }
 __device__ __forceinline__ bool gate_closed(const StepDev &st) { return st.gate != nullptr && *st.gate == 0; }
 
@@ -111,7 +119,7 @@ __device__ inline void finish_row(int32_t row, typename SR::T dot, const uint32_
   // drained (s_waitcnt vmcnt(0)) they are visible system-wide and a report needs no write-back of the XCD's L2.
   // (Measured, R-MAT-23 SSSP / BFS iteration on one GPU, profiles/r03_piece_reporting_cost.log: plain stores + one
   // asynchronous buffer_wbl2 per report and workgroup +5 % at 4 pieces, +11 % at 8; write-through rows +2 % / +0 %.)
-  if (st.done) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (reports(st)) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   else out[at] = to_bits<T>(o);
   if (st.changed) {
     T in = from_bits<T>(st.prev[st.prev_off + at]);
@@ -130,7 +138,7 @@ __device__ inline void finish_row_loaded(int32_t row, typename SR::T dot, uint32
   const int64_t at = row_element(st, row);
   T yv = use_y ? from_bits<T>(y_bits) : SR::identity();
   T o = SR::epilogue(dot, alpha, yv, beta, use_y);
-  if (st.done) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (reports(st)) __hip_atomic_store(out + at, to_bits<T>(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   else out[at] = to_bits<T>(o);
   if (st.changed && SR::differs(from_bits<T>(prev_bits), o, st.delta))
     *st.changed = 1;
@@ -144,11 +152,12 @@ __device__ inline void finish_row_loaded(int32_t row, typename SR::T dot, uint32
 // arrival counts -- the tiled plan's workgroups, the single arrival behind the bit-blocked or CSR-stream kernels --
 // can alternate on one matrix without the word running ahead of the rounds.
 __device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
+  uint32_t *done = st.pcs->done, *done_host = st.pcs->done_host;
   for (int c = c0; c < c1; c++) {
-    const uint32_t n = __hip_atomic_fetch_add(st.done + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t n = __hip_atomic_fetch_add(done + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (n == st.expected) {
-      __hip_atomic_store(st.done + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(st.done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(done + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -158,8 +167,8 @@ __device__ inline void pieces_arrive(const StepDev &st, int c0, int c1) {
 static __global__ void report_all_pieces(StepDev st) {
   // (launched behind the kernels that wrote the rows: a kernel boundary, their write-through stores are complete)
   if (threadIdx.x == 0 && blockIdx.x == 0)
-    for (int c = 0; c < st.n_pieces; c++)
-      __hip_atomic_store(st.done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int c = 0; c < st.pcs->n_pieces; c++)
+      __hip_atomic_store(st.pcs->done_host + c, st.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 
@@ -649,7 +658,11 @@ struct TileChunk { int32_t tile, s, e, hs, pdelta, ob0, pad1, pad2; };
 // r0/nr: rows of the bin; csr0: CSR position of its first entry; n: products incl. padding;
 // pstart: where the bin's slots start in pslot[] (bin-major); gb0 / pt0: its first 64-group block in
 // gblk[] / its first piece in ptab[].
-struct RowBin { int32_t r0, nr, csr0, gb0, n, pstart, pad0, pt0; };
+// (field order: the second 16 bytes are all that phase 2's loader waves need of a bin -- they fetch three bins ahead,
+// one s_load_dwordx4 each instead of the whole record: 12 scalar registers less in a kernel that ran out of them)
+struct RowBin { int32_t r0, nr, csr0, pad0, gb0, n, pstart, pt0; };
+struct RowBinL { int32_t gb0, n, pstart, pt0; };   // a bin as the loaders see it
+static_assert(sizeof(RowBin) == 32 && offsetof(RowBin, gb0) == 16 && sizeof(RowBinL) == 16, "the loaders read the second half of a RowBin");
 
 // Value coding (VC): when the matrix holds at most 256 distinct 4-byte values (always true for
 // pattern files, and for every file once the reference's int narrowing -- quirk A-3 -- has been
@@ -711,7 +724,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     const TileChunk ch, uint32_t *xs, uint32_t *ds, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const bool skip_dead_tiles, Hook staged = NoHook()) {
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const bool skip_dead_tiles, uint32_t *__restrict__ tile_live,
+    Hook staged = NoHook()) {
   using T = typename SR::T;
   constexpr int U = VC ? P1U_VC : P1U;
   // skip_dead_tiles (workgroup-uniform): when every x word of the tile is absorbing (SR::absorbing: an unreached vertex
@@ -763,6 +777,11 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     bool live = true;
     if (may_skip) live = __syncthreads_or(live_word ? 1 : 0) != 0;
     else __syncthreads();
+    // tile_live (launches whose phase 2 reads the pieces through tiled_mark_dead's table): every work item of the tile
+    // says the same; a dead tile's products are then neither written here nor read there
+    int t_here = tid;
+    asm volatile("" : "+v"(t_here));   // (compared here: kept from the top of the kernel, the lane mask of tid == 0 spilled scalar registers)
+    if (may_skip && tile_live != nullptr && t_here == 0) tile_live[ch.tile] = live ? 1u : 0u;
     staged();
     if (live) request_first();
     return live;
@@ -849,7 +868,9 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     uint32_t oa[U], obb[U];
     int g0 = gs + tid;
     const bool live = stage([&]() { load(g0, va, ca, oa); });
-    if (!live) {
+    if (!live && tile_live != nullptr) {
+      // a dead tile whose pieces phase 2 will not read: nothing to write
+    } else if (!live) {
       // a dead tile: every block of 64 groups stores identity products where its own would have gone
       // (obase[b + 1] - obase[b] products: the table carries one entry behind the last block)
       const uint4 id4 = make_uint4(ident, ident, ident, ident);
@@ -952,7 +973,8 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     const TileChunk *__restrict__ chunks, const void *__restrict__ tval_or_code,
     const uint32_t *__restrict__ vdict, const uint16_t *__restrict__ tcol,
     const uint32_t *__restrict__ gdest, const uint32_t *__restrict__ obase, const uint32_t *__restrict__ x, int32_t cols,
-    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate, int32_t skip_dead_tiles) {
+    uint32_t *__restrict__ P, uint32_t *__restrict__ partial, const int32_t *gate, int32_t skip_dead_tiles,
+    uint32_t *__restrict__ tile_live) {
   __shared__ uint32_t xs[TCOLS + 4];
   __shared__ uint32_t ds[VC == 3 ? VDICT16 : (VC ? VDICT : 1)];
   static_assert(TBS * 4 == VDICT16, "one 16-byte load per thread stages the two-byte dictionary");
@@ -962,7 +984,7 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
   SH_STAT(const uint64_t st_t0 = __builtin_amdgcn_s_memrealtime(); __shared__ uint64_t st_staged;)
   SH_STAT(auto stamp = [&]() { if (threadIdx.x == 0) st_staged = __builtin_amdgcn_s_memrealtime(); };)
 #ifdef SH_STATS
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0, stamp);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0, tile_live, stamp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && g_p1_stats) {   // per chunk: kind, entries, start, staged, end (100 MHz ticks)
@@ -970,8 +992,23 @@ __global__ __launch_bounds__(TBS) void spmv_tiled_phase1(
     S[0] = ch.hs <= ch.s; S[1] = (uint64_t)(ch.e - ch.s); S[2] = st_t0; S[3] = st_staged; S[4] = __builtin_amdgcn_s_memrealtime();
   }
 #else
-  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0);
+  tiled_phase1_chunk<SR, VC>(ch, xs, ds, tval_or_code, vdict, tcol, gdest, obase, x, cols, P, partial, skip_dead_tiles != 0, tile_live);
 #endif
+}
+
+// Dead pieces (semirings with absorbing words: the first iterations of a search touch a handful of column tiles).
+// Between the phases of such a launch: the piece table phase 2 reads, with the pieces of the tiles phase 1 found dead
+// (tile_live) replaced by PIECE_DEAD -- phase 2's loaders then fetch ONE group of identity words (written here, behind
+// the last product of P) instead of the piece: a cache hit per wave-instruction instead of ~215 bytes of HBM per
+// piece, and phase 1 did not write those products either.  ~2 us for 2.2 M pieces.
+constexpr int32_t PIECE_DEAD = INT32_MIN;
+static __global__ void tiled_mark_dead(const int32_t *__restrict__ ptab, const uint16_t *__restrict__ ptile, const uint32_t *__restrict__ tile_live,
+                                       int32_t *__restrict__ ptab_live, int64_t n_pieces, uint32_t *__restrict__ ident_group, uint32_t ident,
+                                       const int32_t *gate) {
+  if (gate != nullptr && *gate == 0) return;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < 4) ident_group[k] = ident;
+  if (k < n_pieces) ptab_live[k] = tile_live[ptile[k]] ? ptab[k] : PIECE_DEAD;
 }
 
 // The prefetch of phase 2 goes through inline-asm loads.  hipcc tracks vmcnt only for loads it
@@ -1053,19 +1090,25 @@ __device__ __forceinline__ void tiled_phase2_run(
   // lane arrives.  (The loaders store nothing: their prefetch window stays in flight.)
   int reported = 0;   // pieces [0, reported) reported
   auto report = [&](int j_done) {
-    if (st.done == nullptr || reported >= st.n_pieces) return;
+    if (!reports(st)) return;
+    const int n_pieces = st.pcs->n_pieces;
+    if (reported >= n_pieces) return;
     const int next_bin = j_done < nb ? b0 + j_done * stride : 0x7FFFFFFF;
     int upto = reported;
-    while (upto < st.n_pieces && st.piece_bin_end[upto] <= next_bin) upto++;
+    while (upto < n_pieces && st.pcs->piece_bin_end[upto] <= next_bin) upto++;
     if (upto == reported) return;
-    if (tid >= P2S_LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__builtin_amdgcn_readfirstlane(tid) >= P2S_LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a reducer wave; wave-uniform test)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid == P2S_LD) {
+    int t_here = tid;
+    asm volatile("" : "+v"(t_here));   // (compared here, not once in front of the bin loop: see the note at `chg` below)
+    if (t_here == P2S_LD) {
       // the changed word travels with the last piece: it was raised by plain stores (millions of rows may raise it: they
       // stay in the XCD's L2); this workgroup's share of it is written through once, ahead of its last arrival
-      if (upto == st.n_pieces && st.changed != nullptr &&
-          __hip_atomic_load(st.changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(st.changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      int32_t *chg = st.changed;
+      asm volatile("" : "+s"(chg));   // (the test stays here: hoisted out of the bin loop its lane mask was one scalar pair too many -- a spill)
+      if (upto == n_pieces && chg != nullptr &&
+          __hip_atomic_load(chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(chg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       pieces_arrive(st, reported, upto);
@@ -1076,7 +1119,8 @@ __device__ __forceinline__ void tiled_phase2_run(
     sc.cnt[tid] = 0;
   lds_barrier();
 
-  if (tid < P2S_LD) {
+  static_assert(P2S_LD % 64 == 0, "a wave is all loader or all reducer");
+  if (__builtin_amdgcn_readfirstlane(tid) < P2S_LD) {   // (wave-uniform: a scalar branch, no exec mask saved across a role's body)
     // ------------------------------------------------------------------ loaders
     const v4u32 *P4 = reinterpret_cast<const v4u32 *>(P);
     // Where the products of step q = 4*j + quarter lie in P.  The bin's groups are laid out piece by piece (one piece
@@ -1087,12 +1131,15 @@ __device__ __forceinline__ void tiled_phase2_run(
     // bin: cache hits) and adds its group index.
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto record_of = [&](const RowBin &bn, int quarter, int k) -> uint4 {
+    auto lbin_at = [&](int j) -> RowBinL {   // clamped: one scalar load of 16 bytes
+      return *reinterpret_cast<const RowBinL *>(reinterpret_cast<const char *>(bins + (b0 + min(j, nb - 1) * stride)) + offsetof(RowBin, gb0));
+    };
+    auto record_of = [&](const RowBinL &bn, int quarter, int k) -> uint4 {
       const int nblk = max((bn.n / 4 + 63) / 64, 1);
       const int blk = min(quarter * (P2S_Q / 64) + k * (P2S_LD / 64) + wave, nblk - 1);   // wave-uniform: a scalar load
       return gblk[bn.gb0 + blk];
     };
-    auto ptab_index = [&](const RowBin &bn, const uint4 rec) -> const int32_t * {
+    auto ptab_index = [&](const RowBinL &bn, const uint4 rec) -> const int32_t * {
       const uint32_t below = __builtin_amdgcn_mbcnt_hi(rec.y, __builtin_amdgcn_mbcnt_lo(rec.x, 0u));
       const uint32_t own = ((lane < 32 ? rec.x >> lane : rec.y >> (lane - 32)) & 1u);
       return ptab + bn.pt0 + max((int)(rec.z + below + own) - 1, 0);
@@ -1101,17 +1148,17 @@ __device__ __forceinline__ void tiled_phase2_run(
     // hundred cycles; asked for and used in the same step it cost 2 us per bin): rec[] always holds the records
     // of the step whose words issue_gs() requests next.
     uint4 rec[P2S_K];
-    auto fetch_rec = [&](const RowBin &bn, int quarter) {
+    auto fetch_rec = [&](const RowBinL &bn, int quarter) {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++)
         rec[k] = record_of(bn, quarter, k);
     };
-    auto issue_gs = [&](const RowBin &bn, uint32_t (&g)[P2S_K]) {
+    auto issue_gs = [&](const RowBinL &bn, uint32_t (&g)[P2S_K]) {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++)
         async_load(g[k], ptab_index(bn, rec[k]));
     };
-    auto issue_ps = [&](const RowBin &bn, int quarter, const uint32_t (&g)[P2S_K], v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K]) {
+    auto issue_ps = [&](const RowBinL &bn, int quarter, const uint32_t (&g)[P2S_K], v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K]) {
       const int n4 = max(bn.n / 4, 1);
       const v2u32 *S4 = reinterpret_cast<const v2u32 *>(pslot + bn.pstart);
 #pragma unroll
@@ -1125,7 +1172,9 @@ __device__ __forceinline__ void tiled_phase2_run(
 #if defined(SH_DBG_P2) && (SH_DBG_P2 & 1)   // tools builds (wrong results): P read bin-major, i.e. sequentially
         const int32_t pg = max(0, min(bn.pstart / 4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
 #else
-        const int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
+        int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
+        // a piece of a dead tile (tiled_mark_dead): the group of identity words behind the last product
+        if (SR::has_absorbing && (int32_t)g[k] == PIECE_DEAD) pg = last_group + 1;
 #endif
         async_load(p[k], P4 + pg);
       }
@@ -1137,7 +1186,7 @@ __device__ __forceinline__ void tiled_phase2_run(
                    :
                    : "memory");
     };
-    auto scatter = [&](uint32_t *img, const RowBin &bn, int quarter, const v4u32 (&p)[P2S_K], const v2u32 (&s)[P2S_K]) {
+    auto scatter = [&](uint32_t *img, const RowBinL &bn, int quarter, const v4u32 (&p)[P2S_K], const v2u32 (&s)[P2S_K]) {
       const int n4 = bn.n / 4;
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
@@ -1159,9 +1208,9 @@ __device__ __forceinline__ void tiled_phase2_run(
         img[min(s3, (uint32_t)TBIN)] = p[k].w;
       }
     };
-    RowBin cur = bin_at(0), nxt = bin_at(1), nxt2 = bin_at(2);
+    RowBinL cur = lbin_at(0), nxt = lbin_at(1), nxt2 = lbin_at(2);
     // step q + d (d = 2, 3) seen from step s of the current bin: which bin, which step in it
-    auto bin_of = [&](int s_plus_d) -> const RowBin & {
+    auto bin_of = [&](int s_plus_d) -> const RowBinL & {
       return s_plus_d < P2S_NS ? cur : (s_plus_d < 2 * P2S_NS ? nxt : nxt2);
     };
     v4u32 p[2][P2S_K];
@@ -1171,7 +1220,7 @@ __device__ __forceinline__ void tiled_phase2_run(
     {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
-        const RowBin &b1 = bin_of(1);
+        const RowBinL &b1 = bin_of(1);
         g[0][k] = (uint32_t)*ptab_index(cur, record_of(cur, 0, k));
         g[1][k] = (uint32_t)*ptab_index(b1, record_of(b1, 1 % P2S_NS, k));
       }
@@ -1198,7 +1247,7 @@ __device__ __forceinline__ void tiled_phase2_run(
         }
         cur = nxt;
         nxt = nxt2;
-        nxt2 = bin_at(j + 3);
+        nxt2 = lbin_at(j + 3);
       } else {
         SH_TIMED(pf_bar, lds_barrier())   // MID of the last reduction
       }
@@ -1229,7 +1278,11 @@ __device__ __forceinline__ void tiled_phase2_run(
         // runs under the reduction (R-MAT-23 (min,+) step: phase 2 +50..70 us against a launch without y when they were
         // requested behind MID2; +20 us now: profiles/r03_epilogue_probe_{before,after}.json)
         uint32_t yw[P2S_RPU], pw[P2S_RPU];
-        const bool same_words = use_y && st.changed != nullptr && st.prev + st.prev_off == y;
+        const uint32_t *yq = y;
+        asm volatile("" : "+s"(yq));   // (not hoisted out of the bin loop: as a loop-invariant lane mask it was the scalar pair that spilled)
+        const int32_t *chq = st.changed;
+        asm volatile("" : "+s"(chq));
+        const bool same_words = use_y && chq != nullptr && st.prev + st.prev_off == yq;
         if (staged) {
 #pragma unroll
           for (int k = 0; k < P2S_RPU; k++) {
@@ -1238,7 +1291,7 @@ __device__ __forceinline__ void tiled_phase2_run(
             if (i < prev.nr) {
               const int64_t at = row_element(st, prev.r0 + i);
               if (use_y) yw[k] = y[at];
-              if (st.changed != nullptr && !same_words) pw[k] = st.prev[st.prev_off + at];
+              if (chq != nullptr && !same_words) pw[k] = st.prev[st.prev_off + at];
             }
           }
         }

@@ -78,6 +78,7 @@ struct TiledHost {
   std::vector<LongRow> heavy;        // rows pre-reduced in phase 1: {row, slot0, nslots}
   std::vector<uint32_t> tval, gdest, gblk, lrp, obase;   // gblk: per 64 product groups of a bin {piece-start mask lo, hi, pieces started before, 0}
   std::vector<int32_t> ptab;                      // per (bin, piece): P group index of the piece start - its group index inside the bin
+  std::vector<uint16_t> ptile;                    // per (bin, piece): its column tile (which pieces a tile of absorbing x words makes dead)
   std::vector<uint8_t> tcode;        // value coding (see kernels.hip.h): codes instead of tval
   std::vector<uint32_t> vdict;       // empty = raw values
   int vdict_used = 0;
@@ -268,6 +269,7 @@ struct TiledDevArrays {
   uint8_t *tcode = nullptr;
   uint32_t *tval = nullptr, *gdest = nullptr, *gblk = nullptr, *obase = nullptr, *lrp = nullptr;
   int32_t *ptab = nullptr;
+  uint16_t *ptile = nullptr;
   size_t n_tcol = 0, n_pslot = 0, n_tcode = 0, n_tval = 0, n_gdest = 0, n_gblk = 0, n_obase = 0, n_lrp = 0, n_ptab = 0;
   void release();   // frees what is still set (a builder that failed half-way; the caller after adopting nothing)
 };

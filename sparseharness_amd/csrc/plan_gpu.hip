@@ -30,7 +30,7 @@
 namespace sh {
 
 void TiledDevArrays::release() {
-  for (void *p : {(void *)tcol, (void *)pslot, (void *)tcode, (void *)tval, (void *)gdest, (void *)gblk, (void *)obase, (void *)lrp, (void *)ptab})
+  for (void *p : {(void *)tcol, (void *)pslot, (void *)tcode, (void *)tval, (void *)gdest, (void *)gblk, (void *)obase, (void *)lrp, (void *)ptab, (void *)ptile})
     if (p) (void)hipFree(p);
   *this = TiledDevArrays();
 }
@@ -292,11 +292,12 @@ __global__ void k_fill_light(int64_t L, const uint32_t *__restrict__ iB, const u
 }
 // piece tables, one thread per piece in B-order (= its index in ptab[])
 __global__ void k_piece_tables(const uint32_t *__restrict__ pB, const uint64_t *__restrict__ offB, const uint32_t *__restrict__ p_bin,
-                               const uint64_t *__restrict__ sP, const RowBin *__restrict__ bins, int64_t NP, int32_t *__restrict__ ptab,
-                               uint32_t *__restrict__ gblk) {
+                               const uint32_t *__restrict__ p_tile, const uint64_t *__restrict__ sP, const RowBin *__restrict__ bins, int64_t NP,
+                               int32_t *__restrict__ ptab, uint16_t *__restrict__ ptile, uint32_t *__restrict__ gblk) {
   const int64_t k = GID;
   if (k >= NP) return;
   const uint32_t p = pB[k];
+  ptile[k] = (uint16_t)p_tile[p];
   const RowBin b = bins[p_bin[p]];
   const int64_t g_in_bin = ((int64_t)offB[k] - b.pstart) / 4;
   ptab[k] = (int32_t)((int64_t)(sP[p] / 4) - g_in_bin);
@@ -929,6 +930,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   GT(hipMalloc((void **)&D.pslot, D.n_pslot * 2 + SLACK_WIDE));
   GT(hipMalloc((void **)&D.gblk, D.n_gblk * 4 + SLACK_WIDE));
   GT(hipMalloc((void **)&D.ptab, D.n_ptab * 4 + SLACK_WIDE));
+  GT(hipMalloc((void **)&D.ptile, D.n_ptab * 2 + SLACK_WIDE));
   GT(hipMalloc((void **)&D.obase, D.n_obase * 4 + SLACK_WIDE));
   if (coded) {
     D.n_tcode = tcode_bytes(H.code_bits, H.stream_len);
@@ -945,13 +947,14 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   GT(hipMemsetAsync(D.pslot, 0xFF, D.n_pslot * 2, stream));
   GT(hipMemsetAsync(D.gblk, 0, D.n_gblk * 4, stream));
   GT(hipMemsetAsync(D.ptab, 0, D.n_ptab * 4, stream));
+  GT(hipMemsetAsync(D.ptile, 0, D.n_ptab * 2, stream));
   GT(hipMemsetAsync(D.obase, 0, D.n_obase * 4, stream));
   PHASE("  final arrays: malloc + clear");
   // light stream, slots, piece tables
   if (L > 0 && NP > 0) {
     LAUNCH(k_fill_light, L, L, iB, pid1, p_first, cscan, p_np, p_ns, p_spos, p_off, binT, info, repscan, jA, d_ci, d_val, d_bins, cols, cd,
            D.tcol, code8, D.tval, D.pslot);
-    LAUNCH(k_piece_tables, NP, pB, offB, p_bin, sP, d_bins, NP, D.ptab, D.gblk);
+    LAUNCH(k_piece_tables, NP, pB, offB, p_bin, p_tile, sP, d_bins, NP, D.ptab, D.ptile, D.gblk);
   }
   LAUNCH(k_gblk_before, (int64_t)H.bins.size(), d_bins, (int64_t)H.bins.size(), D.gblk);
   // heavy stream and gdest

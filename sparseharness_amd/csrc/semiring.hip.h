@@ -14,6 +14,7 @@ struct PlusTimesF32 {
   using T = float;
   static constexpr int id = 0;
   __device__ static inline T identity() { return 0.0f; }
+  static constexpr uint32_t identity_bits = 0u;   // (the same word for host code)
   // absorbing(x): mul(x, a) == identity() for every a the matrix may hold -- a column tile of such x words contributes
   // nothing and phase 1 of the tiled plan need not read its entries.  Not for (+,x): 0 * a is -0 for negative a.
   static constexpr bool has_absorbing = false;
@@ -37,6 +38,7 @@ struct MinPlusF32 {
   using T = float;
   static constexpr int id = 1;
   __device__ static inline T identity() { return 3.4028235E38f; }
+  static constexpr uint32_t identity_bits = 0x7F7FFFFFu;
   // |x| == FLT_MAX: FLT_MAX + |a| rounds back to FLT_MAX while |a| < 2^103 (the engine checks the matrix' values)
   static constexpr bool has_absorbing = true;
   __device__ static inline bool absorbing(uint32_t xbits) { return (xbits & 0x7FFFFFFFu) == 0x7F7FFFFFu; }
@@ -59,6 +61,7 @@ struct OrAndI32 {
   using T = int32_t;
   static constexpr int id = 2;
   __device__ static inline T identity() { return 0; }
+  static constexpr uint32_t identity_bits = 0u;
   static constexpr bool has_absorbing = true;
   __device__ static inline bool absorbing(uint32_t xbits) { return xbits == 0u; }
   __device__ static inline T mul(T x, T a) { return (x != 0) && (a != 0); } // bool_and
@@ -79,6 +82,7 @@ struct MaxMinI32 {
   using T = int32_t;
   static constexpr int id = 3;
   __device__ static inline T identity() { return INT32_MIN; }
+  static constexpr uint32_t identity_bits = 0x80000000u;
   static constexpr bool has_absorbing = true;
   __device__ static inline bool absorbing(uint32_t xbits) { return xbits == 0x80000000u; }
   __device__ static inline T mul(T x, T a) { return x < a ? x : a; }       // int_min

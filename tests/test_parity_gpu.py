@@ -266,7 +266,7 @@ def test_iterate_matches_oracle_on_rmat(eng, cases, sr):
 
 
 def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
-    """<= 256 distinct values -> one-byte codes in the tiled stream; more -> raw values; always lossless."""
+    """<= 256 distinct values -> one-byte codes in the tiled stream; <= 4096 -> two-byte codes; more -> raw values; always lossless."""
     if plan != "tiled":
         pytest.skip("value coding belongs to the tiled plan")
     monkeypatch.setenv("SH_VALCODE", "auto")
@@ -283,16 +283,19 @@ def test_value_coding_is_chosen_by_the_data(eng, cases, plan, monkeypatch):
     A = eng.upload_csr(n, n, rp, ci, va)
     assert "values=raw" in A.describe()
     A.free()
-    # exactly 255 distinct non-zero bit patterns (incl. -0.0, inf, a NaN payload) still fit; 256 do not
+    # exactly 255 distinct non-zero bit patterns (incl. -0.0, inf, a NaN payload) still fit one byte; 256 take two-byte
+    # codes, as do 4095; 4096 (+ the padding word) do not fit the 4096-word dictionary: raw
     rng = np.random.default_rng(11)
     m, nnz = 4096, 200_000
     rp = np.linspace(0, nnz, m + 1).astype(np.int32)
     ci = rng.integers(0, m, nnz).astype(np.int32)
-    pool = np.concatenate([np.array([0x80000000, 0x7F800000, 0x7FC00123], np.uint32),
-                           rng.integers(1, 2**31, 252).astype(np.uint32)])
-    for k, want in ((255, "dict8(256)"), (256, "raw")):
-        vb = np.unique(np.concatenate([pool, np.array([0x12345678], np.uint32)]))[:k]
-        assert len(vb) == k
+    pool = np.unique(np.concatenate([np.array([0x80000000, 0x7F800000, 0x7FC00123, 0x12345678], np.uint32),
+                                     rng.integers(1, 2**31, 4200).astype(np.uint32)]))
+    keep = np.array([0x80000000, 0x7F800000, 0x7FC00123], np.uint32)
+    pool = np.concatenate([keep, pool[~np.isin(pool, keep)]])          # the special words among the first 255
+    for k, want in ((255, "dict8(256)"), (256, "dict16(257)"), (4095, "dict16(4096)"), (4096, "raw")):
+        vb = pool[:k]
+        assert len(np.unique(vb)) == k
         vals = vb[rng.integers(0, k, nnz)]
         vals[:k] = vb
         A = eng.upload_csr(m, m, rp, ci, vals.view(np.float32))

@@ -1033,6 +1033,9 @@ __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
 // waves 4-15 REDUCERS, and the LDS holds two product images:
 //   loaders   stream bin j+1 (P pieces via the piece tables, slots) and scatter it into image (j+1)&1;
 //   reducers  reduce bin j out of image j&1 and write the rows.
+// (Round 4 measured where this kernel's time goes -- profiles/r04_phase2_role_profile.log: the loader waves wait for
+// loads 6-12 % of their cycles and for barriers a third; reading P sequentially changes nothing: the kernel is bound by
+// the instructions and LDS latencies of its CU, not by memory.  The reasoning below is how it got its shape.)
 // Why: a CU sustains only what its miss queue holds per memory latency, so HBM time is lost
 // whenever no wave of the CU has a load to issue.  With every wave alternating between "stream
 // a bin" and "reduce a bin" (spmv_tiled_phase2 above, two workgroups per CU) the two workgroups

@@ -191,7 +191,7 @@ constexpr int RL_SHORT = SH_RL_SHORT, RL_MID = 256, RL_WAVE = 4096;
 #define SH_RL_BATCH 8
 #endif
 constexpr int RL_BATCH = SH_RL_BATCH;          // products of a one-lane row read per LDS round trip
-constexpr int RL_BATCH8 = 4, RL_BATCH64 = 8;   // the same for the lanes of an 8-lane / a 64-lane row
+constexpr int RL_BATCH8 = 4, RL_BATCH64 = 4;   // the same for the lanes of an 8-lane / a 64-lane row
 // Spare words behind a product array: a batch starts inside its row and reads on past the row's end with immediate
 // offsets from ONE address register (no clamp per read: three instructions per product less) -- up to 7 words for a
 // one-lane row, 8 * (RL_BATCH8 - 1) + 7 for an 8-lane row, 64 * (RL_BATCH64 - 1) + 63 for a 64-lane row -- so the
@@ -228,9 +228,15 @@ __device__ __forceinline__ typename SR::T sum_to_lane_63(typename SR::T t) {
   return dpp_fold<SR, 0x143, 0xC>(t);   // row_bcast:31 into rows 2 and 3
 }
 
+// (se8 / se64: the listed row's product range, first | one-past-last << 16, noted by the thread that classified the row
+// -- it had both offsets in registers -- so that a cooperative trip is two dependent LDS round trips, list entry and
+// products, not three: the cooperative rows are what phase 2's reducers spend the second half of a bin on, a quarter
+// longer than the loaders' half)
 template <int NT, int NNZ_CAP> struct ReduceScratch {
   uint16_t lst8[NNZ_CAP / (RL_SHORT + 1) + 1];
   uint16_t lst64[NNZ_CAP / (RL_MID + 1) + 1];
+  uint32_t se8[NNZ_CAP / (RL_SHORT + 1) + 1];
+  uint32_t se64[NNZ_CAP / (RL_MID + 1) + 1];
   uint16_t lstB[NNZ_CAP / (RL_WAVE + 1) + 1];
   int32_t cnt[8];   // two sets of {n8, n64, nB, -}: the wave-specialised phase 2 alternates them
   uint32_t wred[NT / 64];
@@ -286,8 +292,9 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
       len1[k] = one[k] ? len : 0;
       acc[k] = SR::identity();
       if (mine && len > RL_SHORT) {
-        if (len <= RL_MID) sc.lst8[atomicAdd(&cnt[0], 1)] = (uint16_t)row;
-        else if (len <= RL_WAVE) sc.lst64[atomicAdd(&cnt[1], 1)] = (uint16_t)row;
+        const uint32_t se = (uint32_t)s[k] | ((uint32_t)(s[k] + len) << 16);   // (offsets stay below 2^15 where this is read: phase 2's bins; the CSR-stream plan's blocks hold 4096 products)
+        if (len <= RL_MID) { const int at = atomicAdd(&cnt[0], 1); sc.lst8[at] = (uint16_t)row; sc.se8[at] = se; }
+        else if (len <= RL_WAVE) { const int at = atomicAdd(&cnt[1], 1); sc.lst64[at] = (uint16_t)row; sc.se64[at] = se; }
         else sc.lstB[atomicAdd(&cnt[2], 1)] = (uint16_t)row;
       }
     }
@@ -324,9 +331,10 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   const int n8 = cnt[0], n64 = cnt[1], nB = cnt[2];
   for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
     const int row = sc.lst8[idx], l = tid & 7;
-    const int e = rp[row + 1] & RP_MASK;
+    const uint32_t se = sc.se8[idx];
+    const int e = (int)(se >> 16);
     T acc = SR::identity();
-    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 8 * RL_BATCH8) {
+    for (int j = (int)(se & 0xFFFFu) + l; j < e; j += 8 * RL_BATCH8) {
       uint32_t v[RL_BATCH8];
 #pragma unroll
       for (int k = 0; k < RL_BATCH8; k++)
@@ -343,9 +351,10 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   SH_STAT(const uint64_t pf_m2 = __builtin_amdgcn_s_memtime(); if (prof) prof[2] += pf_m2 - pf_m1;)
   for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
     const int row = sc.lst64[idx], l = tid & 63;
-    const int e = rp[row + 1] & RP_MASK;
+    const uint32_t se = sc.se64[idx];
+    const int e = (int)(se >> 16);
     T acc = SR::identity();
-    for (int j = (rp[row] & RP_MASK) + l; j < e; j += 64 * RL_BATCH64) {
+    for (int j = (int)(se & 0xFFFFu) + l; j < e; j += 64 * RL_BATCH64) {
       uint32_t v[RL_BATCH64];
 #pragma unroll
       for (int k = 0; k < RL_BATCH64; k++)

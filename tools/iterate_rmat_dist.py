@@ -37,7 +37,7 @@ out = {"workload": f"rmat-{scale}", "rows": n, "nnz": int(rp[-1]), "n_gpus": wor
 for name, sr, a, b in [("sssp", MIN_PLUS_F32, 0.0, 0.0), ("bfs", OR_AND_I32, 1, 0)]:
     dt = np.int32 if sr == OR_AND_I32 else np.float32
     vals = va.astype(dt)
-    plan = ShardPlan(rp, ci, vals, rank, world, chunks)
+    plan = ShardPlan(rp, ci, vals, rank, world, chunks, semiring=sr)
     step = HipLocalStep(plan, sr, local)
     x0 = np.zeros(n, dt)
     if sr == MIN_PLUS_F32:

@@ -2,7 +2,7 @@
 // reference's counterpart is SparseMatrix::cl_encode on the host, src/sparse_matrix.cpp:122-399).
 //
 // The host builder (engine.hip::build_tiled_plan) walks the matrix bin by bin; here the same layout falls out of
-// sorts and scans (rocPRIM through hipcub) plus one thread per entry / piece / strip:
+// sorts and scans (rocPRIM) plus one thread per entry / piece / strip:
 //
 //   A-order  all entries sorted by (row, tile), stable: a (row, tile) RUN is contiguous, its entries in CSR order.
 //            Per entry: index inside its run, the run's length, its ROLE (first / second entry of a folded pair,
@@ -21,7 +21,9 @@
 // the host builder's emulator and parity tests establish holds for it too.
 #include "plan_common.h"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 #include <cstring>
 #include <string>
@@ -38,6 +40,26 @@ void TiledDevArrays::release() {
 namespace {
 
 constexpr int PBS = 256;
+// rocPRIM's device-wide primitives under the names the builder uses (two-call convention: temporary storage size first)
+template <class In, class Out>
+hipError_t excl_sum(void *t, size_t &b, In in, Out out, int64_t n, hipStream_t s) {
+  using T = typename std::iterator_traits<Out>::value_type;
+  return rocprim::exclusive_scan(t, b, in, out, T(0), (size_t)n, rocprim::plus<T>(), s);
+}
+template <class In, class Out>
+hipError_t incl_sum(void *t, size_t &b, In in, Out out, int64_t n, hipStream_t s) {
+  using T = typename std::iterator_traits<Out>::value_type;
+  return rocprim::inclusive_scan(t, b, in, out, (size_t)n, rocprim::plus<T>(), s);
+}
+template <class In, class Out>
+hipError_t incl_max(void *t, size_t &b, In in, Out out, int64_t n, hipStream_t s) {
+  using T = typename std::iterator_traits<Out>::value_type;
+  return rocprim::inclusive_scan(t, b, in, out, (size_t)n, rocprim::maximum<T>(), s);
+}
+template <class K, class V>
+hipError_t sort_pairs(void *t, size_t &b, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int bit0, int bit1, hipStream_t s) {
+  return rocprim::radix_sort_pairs(t, b, kin, kout, vin, vout, (size_t)n, (unsigned)bit0, (unsigned)bit1, s);
+}
 constexpr uint32_t ROLE_SINGLE = 0, ROLE_FIRST = 1, ROLE_SECOND = 2, ROLE_HEAVY = 3;
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + PBS - 1) / PBS)); }
 inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b) != 0) b++; return b; }
@@ -636,15 +658,15 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   valA_in = pool.get<uint32_t>((size_t)n); jA = pool.get<uint32_t>((size_t)n);
   POOL_OK();
   LAUNCH(k_row_heads, rows, d_rp, rows, head);
-  CUB(hipcub::DeviceScan::InclusiveScan(d_temp_storage, temp_storage_bytes, head, row_of, hipcub::Max(), n, stream));
+  CUB(incl_max(d_temp_storage, temp_storage_bytes, head, row_of, n, stream));
   LAUNCH(k_keys, n, row_of, d_ci, n, cols, tb, keyA_in, valA_in);
-  CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, keyA_in, keyA, valA_in, jA, n, 0, tb + rb, stream));
+  CUB(sort_pairs(d_temp_storage, temp_storage_bytes, keyA_in, keyA, valA_in, jA, n, 0, tb + rb, stream));
   PHASE("  A-order sort");
   // runs, roles
   start_idx = head;   // (head is free again)
   rs = row_of;        // (so is row_of: the keys carry the rows)
   LAUNCH(k_run_starts, n, keyA, n, start_idx);
-  CUB(hipcub::DeviceScan::InclusiveScan(d_temp_storage, temp_storage_bytes, start_idx, rs, hipcub::Max(), n, stream));
+  CUB(incl_max(d_temp_storage, temp_storage_bytes, start_idx, rs, n, stream));
   rep = pool.get<uint32_t>((size_t)n + 1, true);
   hstart = pool.get<uint32_t>((size_t)n + 1, true);
   klen = pool.get<uint32_t>((size_t)n);
@@ -655,8 +677,8 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   POOL_OK();
   LAUNCH(k_roles, n, keyA, rs, d_rp, n, tb, heavy_thr, fold ? 1 : 0, rep, hstart, klen, role);
   LAUNCH(k_info, n, rs, klen, role, n, info);
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, rep, repscan, n + 1, stream));
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, hstart, hscan, n + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, rep, repscan, n + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, hstart, hscan, n + 1, stream));
   PHASE("  runs, roles, scans");
   // lrp (a final array) and the row bins (host: a greedy cut is sequential)
   D.n_lrp = (size_t)rows + 1;
@@ -705,7 +727,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   tileB = pool.get<uint32_t>((size_t)n); iB = pool.get<uint32_t>((size_t)n);
   POOL_OK();
   LAUNCH(k_tile_keys, n, keyA, role, n, tb, (uint32_t)CT, keyB_in, valB_in);
-  CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, keyB_in, tileB, valB_in, iB, n, 0, bits_for((uint64_t)CT), stream));
+  CUB(sort_pairs(d_temp_storage, temp_storage_bytes, keyB_in, tileB, valB_in, iB, n, 0, bits_for((uint64_t)CT), stream));
   if (L > 0) {
     pflag = keyB_in;   // (free after the sort)
     pid1 = valB_in;
@@ -714,8 +736,8 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     binT = pool.get<uint32_t>((size_t)L);
     POOL_OK();
     LAUNCH(k_piece_flags, L, tileB, iB, keyA, bin_of, info, L, tb, pflag, cnt, binT);
-    CUB(hipcub::DeviceScan::InclusiveSum(d_temp_storage, temp_storage_bytes, pflag, pid1, L, stream));
-    CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, cnt, cscan, L + 1, stream));
+    CUB(incl_sum(d_temp_storage, temp_storage_bytes, pflag, pid1, L, stream));
+    CUB(excl_sum(d_temp_storage, temp_storage_bytes, cnt, cscan, L + 1, stream));
     GT(hipMemcpyAsync(&u32tmp, pid1 + (L - 1), 4, hipMemcpyDeviceToHost, stream));
     GT(hipStreamSynchronize(stream));
     NP = u32tmp;
@@ -735,8 +757,8 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     LAUNCH(k_piece_firsts, L, pflag, pid1, tileB, binT, L, NP, p_first, p_tile, p_bin);
     LAUNCH(k_piece_sizes, NP, p_first, cscan, NP, p_np, p_ns, p_g4, p_prods);
   }
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, p_g4, sS, NP + 1, stream));
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, p_prods, sP, NP + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, p_g4, sS, NP + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, p_prods, sP, NP + 1, stream));
   LAUNCH(k_bounds, NP, p_tile, sS, sP, NP, tbS, teS, tbP, teP);
   h64a.resize((size_t)CT); h64b.resize((size_t)CT); h64c.resize((size_t)CT); h64d.resize((size_t)CT);
   GT(hipMemcpyAsync(h64a.data(), tbS, (size_t)CT * 8, hipMemcpyDeviceToHost, stream));
@@ -776,11 +798,11 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     POOL_OK();
     if (NP > 0) {
       LAUNCH(k_iota, NP, piota, NP);
-      CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, p_bin, p_bin_sorted, piota, pB, NP, 0,
+      CUB(sort_pairs(d_temp_storage, temp_storage_bytes, p_bin, p_bin_sorted, piota, pB, NP, 0,
                                              bits_for((uint64_t)std::max<int64_t>(n_bins, 1) - 1), stream));
       LAUNCH(k_gather64, NP, p_prods, pB, NP, prodsB);
     }
-    CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, prodsB, offB, NP + 1, stream));
+    CUB(excl_sum(d_temp_storage, temp_storage_bytes, prodsB, offB, NP + 1, stream));
     if (NP > 0) {
       // kidx[k] = k as a 64-bit "scan", so that k_bounds yields the bins' first piece / one past their last piece
       // (s1 = kidx, s2 = offB)
@@ -827,19 +849,19 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   if (NC > 0) {
     LAUNCH(k_cells, n, hstart, hscan, keyA, klen, n, tb, c_tile, c_row, c_cnt);
     LAUNCH(k_iota, NC, ciota, NC);
-    CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, c_tile, tileT, ciota, cT, NC, 0, tb, stream));
+    CUB(sort_pairs(d_temp_storage, temp_storage_bytes, c_tile, tileT, ciota, cT, NC, 0, tb, stream));
     LAUNCH(k_cell_padded, NC, cT, c_cnt, NC, padT);
   }
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, padT, hposT, NC + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, padT, hposT, NC + 1, stream));
   if (NC > 0) {
     LAUNCH(k_bounds, NC, tileT, hposT, hposT, NC, hb, he, hb2, he2);
     LAUNCH(k_cell_pos, NC, cT, tileT, hposT, hb, NC, c_pos, c_glob, c_nparts);
   }
   // (cells are numbered in A-order = (row, tile): the scan of their partial counts is slot0 + part0 of the host builder)
-  CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, c_nparts, c_part, NC + 1, stream));
+  CUB(excl_sum(d_temp_storage, temp_storage_bytes, c_nparts, c_part, NC + 1, stream));
   if (NC > 0) {
     LAUNCH(k_row_first_flags, NC, c_row, NC, rf);
-    CUB(hipcub::DeviceScan::InclusiveSum(d_temp_storage, temp_storage_bytes, rf, rfscan, NC, stream));
+    CUB(incl_sum(d_temp_storage, temp_storage_bytes, rf, rfscan, NC, stream));
     LAUNCH(k_heavy_rows, NC, c_row, rf, rfscan, c_part, NC, d_hv);
     LAUNCH(k_heavy_rows_fix, n_heavy, d_hv, n_heavy);
   }
@@ -971,7 +993,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
     POOL_OK();
     if (NB > 0) {
       LAUNCH(k_block_counts, NB * 64, D.tcol, d_ob0, d_run_start, d_run_len, CT, NB, bcnt);
-      CUB(hipcub::DeviceScan::ExclusiveSum(d_temp_storage, temp_storage_bytes, bcnt, bscan, NB + 1, stream));
+      CUB(excl_sum(d_temp_storage, temp_storage_bytes, bcnt, bscan, NB + 1, stream));
       LAUNCH(k_scale4, NB + 1, bscan, NB + 1, D.obase);   // (the entry behind the last block = all products: obase[b + 1] - obase[b] = products of block b)
       // every tile's products must end where the next tile's begin (the host builder's consistency check)
       GT(hipMemcpyAsync(&u32tmp, bscan + NB, 4, hipMemcpyDeviceToHost, stream));
@@ -1041,11 +1063,11 @@ int build_bits_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t 
   d_start = pool.get<uint32_t>((size_t)ncell + 1);
   POOL_OK();
   LAUNCH(k_row_heads, rows, d_rp, rows, head);
-  CUB(hipcub::DeviceScan::InclusiveScan(d_temp_storage, temp_storage_bytes, head, row_of, hipcub::Max(), n, stream));
+  CUB(incl_max(d_temp_storage, temp_storage_bytes, head, row_of, n, stream));
   LAUNCH(k_bits_keys, n, row_of, d_ci, d_val, n, cols, H.n_ct, (uint32_t)ncell, key_in, idx_in);
   // stable: inside a cell the entries keep the order of the CSR walk (rows ascending), so the sub-range of an entry
   // follows from its position
-  CUB(hipcub::DeviceRadixSort::SortPairs(d_temp_storage, temp_storage_bytes, key_in, key, idx_in, jS, n, 0, bits_for((uint64_t)ncell), stream));
+  CUB(sort_pairs(d_temp_storage, temp_storage_bytes, key_in, key, idx_in, jS, n, 0, bits_for((uint64_t)ncell), stream));
   LAUNCH(k_bits_bounds, n, key, n, (uint32_t)ncell, cstart, cend);
   GT(hipMemcpyAsync(hs.data(), cstart, (size_t)ncell * 4, hipMemcpyDeviceToHost, stream));
   GT(hipMemcpyAsync(he.data(), cend, (size_t)ncell * 4, hipMemcpyDeviceToHost, stream));

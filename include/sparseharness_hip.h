@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define SH_ABI_VERSION 2   /* 2: sh_plan_options lost the fused-launch fields and gained `fold`; sh_csr_footprint, sh_plan_row_work */
+#define SH_ABI_VERSION 3   /* 2: sh_plan_options lost the fused-launch fields and gained `fold`; sh_csr_footprint, sh_plan_row_work;
+                              3: sh_row_pieces gained `gate`; sh_csr_piece_state */
 
 enum {
   SH_OK = 0,
@@ -236,6 +237,9 @@ typedef struct sh_row_pieces {
   int64_t element_of_piece[8];
   int32_t report;
   int32_t reserved;
+  const int32_t *gate;   /* device word or NULL: a launch whose gate word is 0 when it starts returns at once and writes nothing
+                            (what sh_iterate does internally: a caller that enqueues iteration k + 1 before it has read the
+                            flags of iteration k passes the device-side OR of those flags here) */
 } sh_row_pieces;
 int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x, const sh_vec *y,
                         const void *alpha, const void *beta, sh_vec *out, const sh_row_pieces *pieces, double delta,

@@ -31,7 +31,7 @@ class sh_plan_options(C.Structure):
 class sh_row_pieces(C.Structure):
     """Row pieces of sh_spmv_step_pieces (include/sparseharness_hip.h)."""
     _fields_ = [("n_pieces", C.c_int32), ("piece_rows", C.c_int32), ("element_of_piece", C.c_int64 * 8),
-                ("report", C.c_int32), ("reserved", C.c_int32)]
+                ("report", C.c_int32), ("reserved", C.c_int32), ("gate", C.c_void_p)]
 
 
 _vp, _i32, _i64, _u64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int

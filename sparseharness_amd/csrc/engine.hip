@@ -1658,7 +1658,7 @@ int sh_spmv_step_pieces(sh_engine *e, sh_semiring sr, sh_csr *A, const sh_vec *x
   if (out->d == x->d && A->rows > 0)
     return fail(e, SH_EINVAL, "sh_spmv_step_pieces: out must not alias x");
   HIP_TRY(e, hipSetDevice(e->device));
-  StepDev st{changed_flag_device, (const uint32_t *)x->d, 0, delta};
+  StepDev st{changed_flag_device, (const uint32_t *)x->d, 0, delta, pc->gate};
   PieceDev pd{};
   pd.n_pieces = pc->n_pieces;
   pd.piece_rows = pc->piece_rows;

@@ -29,6 +29,8 @@ is reduced by the same code over the same data.
 (the product) calls the C ABI on torch-owned device memory; the CPU tests plug
 the oracle in instead to exercise the sharding + collective logic under gloo.
 """
+import os
+
 import numpy as np
 
 from . import partition
@@ -120,10 +122,12 @@ class HipLocalStep:
             v = self._wrapped[(ptr, n)] = self.engine.wrap(ptr, n)
         return v
 
-    def launch(self, x_cur, y_vec, x_next, alpha, beta, delta):
+    def launch(self, x_cur, y_vec, x_next, alpha, beta, delta, gate=None):
         """All pieces of this rank in one launch: x_next[pieces] = kernel(A, x_cur, y_vec[pieces]); raises the rank's
-        changed word; y_vec is a vector in the layout of x (x_cur itself from the second iteration on)."""
+        changed word; y_vec is a vector in the layout of x (x_cur itself from the second iteration on).  gate: a device
+        int32 tensor or None -- a launch whose gate word is 0 when it starts writes nothing (sh_row_pieces::gate)."""
         C, lay, k = self.C, self.plan.layout, self.plan.rank
+        self.pc.gate = gate.data_ptr() if gate is not None else None
         flag = self._vec(x_next.data_ptr() + lay.flag_index(k) * 4, lay.FLAG_PAD)
         flag.fill(0, np.int32)   # clear my changed word (async, same stream)
         if self.plan.rows == 0:
@@ -220,12 +224,26 @@ class ShardedIteration:
         if dev.type == "cuda":
             torch.cuda.synchronize()
         t_loop = time.perf_counter()
-        while iters < max_iters:
+
+        def fan_out(buf, my_piece, plen):
+            """Direct exchange: my piece to every peer, every peer's piece into its place in `buf`."""
+            ops = []
+            for j in range(world):
+                if j != k:
+                    ops.append(dist.P2POp(dist.isend, my_piece, j))
+                    ops.append(dist.P2POp(dist.irecv, buf[j * plen:(j + 1) * plen], j))
+            return dist.batch_isend_irecv(ops) if ops else []
+
+        def enqueue(x_cur, x_next, first, gate=None):
+            """One iteration's work: the launch, the exchange of every piece, the wait for the exchanges."""
             if not clears_own_flag:
                 x_next[flag_i:flag_i + lay.FLAG_PAD] = 0
             pending = []
-            y_vec = y_lay if iters == 0 else x_cur
-            self.local.launch(x_cur, y_vec, x_next, alpha, beta, delta)
+            y_vec = y_lay if first else x_cur
+            if gate is not None:
+                self.local.launch(x_cur, y_vec, x_next, alpha, beta, delta, gate=gate)
+            else:
+                self.local.launch(x_cur, y_vec, x_next, alpha, beta, delta)
             for c in range(chunks):
                 self.local.wait_piece(c)
                 if exchanging:
@@ -233,19 +251,10 @@ class ShardedIteration:
                     plen = lay.piece_len(c)
                     region = x_next[start:start + length]
                     mine = region[k * plen:(k + 1) * plen]
-
-                    def fan_out(buf, my_piece):
-                        """Direct exchange: my piece to every peer, every peer's piece into its place in `buf`."""
-                        ops = []
-                        for j in range(world):
-                            if j != k:
-                                ops.append(dist.P2POp(dist.isend, my_piece, j))
-                                ops.append(dist.P2POp(dist.irecv, buf[j * plen:(j + 1) * plen], j))
-                        return dist.batch_isend_irecv(ops) if ops else []
                     if dev.type == "cpu":
                         mine = mine.clone()   # gloo does not take an input aliasing the output
                         if self.exchange == "p2p":
-                            pending.extend(fan_out(region, mine))
+                            pending.extend(fan_out(region, mine, plen))
                         else:
                             pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
                     elif dist.get_backend() == "gloo":
@@ -257,7 +266,7 @@ class ShardedIteration:
                             region_h = torch.empty(length, dtype=region.dtype)
                             if self.exchange == "p2p":
                                 region_h[k * plen:(k + 1) * plen] = mine_h
-                                for w in fan_out(region_h, mine_h):
+                                for w in fan_out(region_h, mine_h, plen):
                                     w.wait()
                             else:
                                 dist.all_gather_into_tensor(region_h, mine_h)
@@ -266,15 +275,50 @@ class ShardedIteration:
                             ev.record(side)
                             pending.append(ev)
                     else:
-                        # piece c is complete and visible (the host has seen its report): its exchange need not wait for
-                        # the launch, which is still computing the later pieces on the main stream
+                        # piece c is complete and visible (the host has seen its report, or the exchange follows the launch
+                        # on its own stream): it need not wait for the later pieces of a reporting launch
                         with torch.cuda.stream(side):
                             if self.exchange == "p2p":
-                                pending.extend(fan_out(region, mine))
+                                pending.extend(fan_out(region, mine, plen))
                             else:
                                 pending.append(dist.all_gather_into_tensor(region, mine, async_op=True))
             for w in pending:
                 w.wait()   # (the main stream waits: collective work or the event behind a staged copy)
+
+        # Run-ahead (one piece per rank on the GPU under RCCL: everything of an iteration is stream-ordered): iteration
+        # i + 1 is enqueued BEFORE the host has read the flags of iteration i, behind a device word that holds their OR
+        # -- its launch returns at once when that word is 0 (sh_row_pieces::gate), so a converged loop costs one empty
+        # launch, and the host's enqueue work and wake-up run under the device's work instead of between iterations.
+        run_ahead = in_order and exchanging and dist.get_backend() != "gloo" and os.environ.get("SH_RUN_AHEAD", "1") != "0"
+        if run_ahead:
+            sets = [(torch.zeros(world, dtype=torch.int32, device=dev), torch.zeros(world, dtype=torch.int32).pin_memory(),
+                     torch.zeros((), dtype=torch.int32, device=dev), torch.cuda.Event()) for _ in range(2)]
+
+            def finish(x_next, st):
+                fd, fh, gate_w, ev = st
+                torch.index_select(x_next.view(torch.int32), 0, flag_idx, out=fd)
+                torch.amax(fd, 0, out=gate_w)
+                fh.copy_(fd, non_blocking=True)
+                ev.record()
+            enqueue(x_cur, x_next, True)
+            finish(x_next, sets[0])
+            enq = 1
+            while True:
+                st = sets[iters & 1]
+                if enq < max_iters:   # iteration `enq` reads what iteration `iters` wrote; gated by the flags of `iters`
+                    enqueue(x_next, x_cur, False, gate=st[2])
+                    finish(x_cur, sets[enq & 1])
+                    enq += 1
+                st[3].synchronize()
+                iters += 1
+                x_cur, x_next = x_next, x_cur
+                if not bool(st[1].any()):
+                    converged = True
+                    break
+                if iters >= max_iters:
+                    break
+        while not run_ahead and iters < max_iters:
+            enqueue(x_cur, x_next, iters == 0)
             torch.index_select(x_next.view(torch.int32), 0, flag_idx, out=flags_dev)
             flags_host.copy_(flags_dev, non_blocking=True)
             if copied is not None:

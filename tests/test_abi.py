@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(abi.SIGNATURES) == names, "abi.SIGNATURES and the header disagree"
-    assert lib.sh_abi_version() == 2
+    assert lib.sh_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():

@@ -1139,9 +1139,8 @@ __device__ __forceinline__ void tiled_phase2_run(
     // per column tile); instead of a source address per group (1 B per product of HBM traffic) the plan keeps, per
     // 64 groups, a record {mask of the groups that start a piece, pieces started before the block} -- one scalar
     // load per wave-instruction -- and per piece one word ptab = (P group index of the piece) - (its group index in
-    // the bin): a lane counts the piece starts up to its own group (mbcnt), gathers that word (a table of ~1.2 KB per
+    // the bin): a lane counts the piece starts up to its own group (mbcnt of the mask), gathers that word (a table of ~1.2 KB per
     // bin: cache hits) and adds its group index.
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto lbin_at = [&](int j) -> RowBinL {   // clamped: one scalar load of 16 bytes
       return *reinterpret_cast<const RowBinL *>(reinterpret_cast<const char *>(bins + (b0 + min(j, nb - 1) * stride)) + offsetof(RowBin, gb0));
@@ -1152,9 +1151,14 @@ __device__ __forceinline__ void tiled_phase2_run(
       return gblk[bn.gb0 + blk];
     };
     auto ptab_index = [&](const RowBinL &bn, const uint4 rec) -> const int32_t * {
-      const uint32_t below = __builtin_amdgcn_mbcnt_hi(rec.y, __builtin_amdgcn_mbcnt_lo(rec.x, 0u));
-      const uint32_t own = ((lane < 32 ? rec.x >> lane : rec.y >> (lane - 32)) & 1u);
-      return ptab + bn.pt0 + max((int)(rec.z + below + own) - 1, 0);
+      // pieces started at or before this lane's group = (started before the block) + (bits of the mask up to the lane's).
+      // The mask is shifted down by one on the SCALAR unit so that mbcnt -- bits below the lane -- counts the lane's own
+      // bit too; what falls off (bit 0: the block's first group starts a piece) joins the base.  Two vector
+      // instructions per group instead of seven.
+      const uint64_t m = ((uint64_t)rec.y << 32 | rec.x) >> 1;
+      const int base = max((int)rec.z + (int)(rec.x & 1u) - 1, 0);
+      const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      return ptab + bn.pt0 + base + (int)upto;
     };
     // The records of a step are fetched one step before its piece words are requested (a scalar load takes a few
     // hundred cycles; asked for and used in the same step it cost 2 us per bin): rec[] always holds the records
@@ -1184,7 +1188,8 @@ __device__ __forceinline__ void tiled_phase2_run(
 #if defined(SH_DBG_P2) && (SH_DBG_P2 & 1)   // tools builds (wrong results): P read bin-major, i.e. sequentially
         const int32_t pg = max(0, min(bn.pstart / 4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
 #else
-        int32_t pg = max(0, min((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1), last_group));
+        // (clamped: a stale register must not fault -- one unsigned min: a negative sum wraps to the far end)
+        int32_t pg = (int32_t)min((uint32_t)((int32_t)g[k] + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1)), (uint32_t)last_group);
         // a piece of a dead tile (tiled_mark_dead): the group of identity words behind the last product
         if (SR::has_absorbing && (int32_t)g[k] == PIECE_DEAD) pg = last_group + 1;
 #endif

@@ -1,5 +1,5 @@
 // plan_common.h -- host-side pieces of the x-tiled plan shared by the two builders of its layout: the host builder
-// (engine.hip::build_tiled_plan) and the device builder (plan_gpu.hip::build_tiled_plan_gpu).  Both produce the same
+// (plan_host.h::build_tiled_plan) and the device builder (plan_gpu.hip::build_tiled_plan_gpu).  Both produce the same
 // arrays, byte for byte; the policies that are not per-entry work -- value coding, the phase-1 work items -- live here
 // once.  (The layout itself replaces SparseMatrix::cl_encode of the reference, src/sparse_matrix.cpp:122-399.)
 #pragma once
@@ -276,7 +276,7 @@ struct TiledDevArrays {
 // slack bytes behind the arrays (the host path's DEV_ARRAY calls use the same numbers)
 constexpr size_t SLACK_TCODE = 64, SLACK_WIDE = 16;
 
-// The same layout as engine.hip::build_tiled_plan, built on the device from the CSR arrays already there (plan_gpu.hip).
+// The same layout as plan_host.h::build_tiled_plan, built on the device from the CSR arrays already there (plan_gpu.hip).
 // 1: built; 0: the plan does not apply (the host builder's own refusals: it would say no as well); -1: a device step
 // failed (`why` says which) and the caller falls back to the host builder.
 int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *h_rp, const int32_t *d_rp,

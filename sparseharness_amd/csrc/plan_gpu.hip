@@ -1,7 +1,7 @@
 // plan_gpu.hip -- the x-tiled plan's layout built ON THE DEVICE from the CSR arrays (VERDICT r2 "missing" #4; the
 // reference's counterpart is SparseMatrix::cl_encode on the host, src/sparse_matrix.cpp:122-399).
 //
-// The host builder (engine.hip::build_tiled_plan) walks the matrix bin by bin; here the same layout falls out of
+// The host builder (plan_host.h::build_tiled_plan) walks the matrix bin by bin; here the same layout falls out of
 // sorts and scans (rocPRIM) plus one thread per entry / piece / strip:
 //
 //   A-order  all entries sorted by (row, tile), stable: a (row, tile) RUN is contiguous, its entries in CSR order.

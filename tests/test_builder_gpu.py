@@ -1,4 +1,4 @@
-"""The device-side builder of the x-tiled layout (csrc/plan_gpu.hip) against the host builder (engine.hip::
+"""The device-side builder of the x-tiled layout (csrc/plan_gpu.hip) against the host builder (plan_host.h::
 build_tiled_plan): every array of the layout must come out the same, byte for byte -- the host builder is itself
 checked by the host emulator (tests/test_plan_cpu.py) and by the parity tests, so equality carries all of that over.
 The comparison lives in the tools build of the engine (sh_debug_compare_builds, `make -C sparseharness_amd/csrc emulate`);

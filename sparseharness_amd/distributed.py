@@ -25,6 +25,12 @@ iteration besides the report words) and waits for exactly that copy.  Results ar
 single-GPU sh_iterate for every world size and chunk count, because each row
 is reduced by the same code over the same data.
 
+Variants of steps 2-4 (round 4): with ONE piece per rank nothing is reported or polled -- the exchange is enqueued behind
+the launch on the launch's own stream, and iteration k + 1 is enqueued before the host has read the flags of iteration
+k, behind a device word holding their OR (sh_row_pieces::gate: a launch whose gate reads 0 writes nothing), so the
+host's work runs under the device's; `exchange="p2p"` (SH_EXCHANGE) replaces the all-gather by a grouped batch of
+isend / irecv pairs, every rank's piece straight to every peer (the direct xGMI fan-out of SURVEY.md 5 / 8e).
+
 `LocalStep` is the seam between this driver and the device: `HipLocalStep`
 (the product) calls the C ABI on torch-owned device memory; the CPU tests plug
 the oracle in instead to exercise the sharding + collective logic under gloo.

@@ -186,3 +186,58 @@ def test_bit_plan_on_a_matrix_spanning_several_blocks(emu):
     assert emu.sh_debug_emulate_bits(rows, cols, len(ci), _p(rp), _p(ci), _p(vals), _p(x), _p(y), _p(st)) == 0
     np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, vals, x, 2))
     assert st[3] == 3 and st[4] == 3 and st[2] <= 9
+
+
+def test_emulated_plan_on_drawn_small_shapes(emu):
+    """Shapes nobody wrote down: hypothesis draws small matrices -- empty ones, a single row or column, all entries in
+    one row, duplicate (row, column) entries, columns out of range, rows just below and above the heavy threshold -- and
+    every one must come out of the walked layout exactly as out of the plain CSR product, under folding on and off."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import strategies as S
+
+    @hyp.settings(max_examples=60, deadline=None, derandomize=True,
+                  suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(rows=S.integers(1, 400), cols=S.sampled_from([1, 2, 7, 300, 32_759, 32_760, 32_761, 65_520, 70_001]),
+               kind=S.sampled_from(["sparse", "dense_rows", "one_row", "duplicates", "empty", "near_heavy"]),
+               seed=S.integers(0, 2 ** 31 - 1), fold=S.sampled_from([0, 1]), oob=S.booleans())
+    def run(rows, cols, kind, seed, fold, oob):
+        rng = np.random.default_rng(seed)
+        if kind == "empty":
+            deg = np.zeros(rows, np.int64)
+        elif kind == "one_row":
+            deg = np.zeros(rows, np.int64)
+            deg[rng.integers(0, rows)] = rng.integers(1, 5000)
+        elif kind == "dense_rows":
+            deg = rng.integers(0, 60, rows).astype(np.int64)
+        elif kind == "near_heavy":
+            deg = rng.poisson(3, rows).astype(np.int64)
+            thr = max(512, 8 * ((cols + 32_759) // 32_760))
+            for h in rng.integers(0, rows, 3):
+                deg[h] = thr + rng.integers(-2, 3)
+        else:
+            deg = rng.poisson(4, rows).astype(np.int64)
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum(deg)
+        nnz = int(rp[-1])
+        ci = rng.integers(0, cols, nnz).astype(np.int32)
+        if kind == "duplicates" and nnz:
+            ci = (ci % min(cols, 3)).astype(np.int32)       # many entries of a row share a column
+        if oob and nnz:
+            ci[rng.integers(0, nnz, max(1, nnz // 20))] = rng.choice([-1, cols, 2 ** 31 - 1])
+        va = rng.integers(1, 17, nnz).astype(np.float32)
+        for sem in (0, 2):
+            vals = va if sem == 0 else va.astype(np.int32)
+            rc, y, st, x = emulate(emu, rows, cols, rp, ci, vals, sem, fold=fold)
+            assert rc == 0, (rc, st)
+            assert st["poison_reads"] == 0, st
+            np.testing.assert_array_equal(y, exact(rows, cols, rp, ci, vals, x, sem), err_msg=str((rows, cols, kind, seed, fold, oob, sem, st)))
+        # the same matrix through the bit-blocked (or,and) layout, a sparse and a dense x
+        vals = va.astype(np.int32)
+        for density in (0.05, 1.0):
+            xb = (rng.random(cols) < density).astype(np.int32)
+            yb = np.full(rows, -1, np.int32)
+            stb = np.zeros(8, np.int64)
+            assert emu.sh_debug_emulate_bits(rows, cols, nnz, _p(rp), _p(ci), _p(vals), _p(xb), _p(yb), _p(stb)) == 0
+            np.testing.assert_array_equal(yb, exact(rows, cols, rp, ci, vals, xb, 2), err_msg=str((rows, cols, kind, seed, oob, density)))
+
+    run()

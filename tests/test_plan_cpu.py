@@ -195,7 +195,7 @@ def test_emulated_plan_on_drawn_small_shapes(emu):
     hyp = pytest.importorskip("hypothesis")
     from hypothesis import strategies as S
 
-    @hyp.settings(max_examples=60, deadline=None, derandomize=True,
+    @hyp.settings(max_examples=400, deadline=None, derandomize=True,
                   suppress_health_check=list(hyp.HealthCheck))
     @hyp.given(rows=S.integers(1, 400), cols=S.sampled_from([1, 2, 7, 300, 32_759, 32_760, 32_761, 65_520, 70_001]),
                kind=S.sampled_from(["sparse", "dense_rows", "one_row", "duplicates", "empty", "near_heavy"]),

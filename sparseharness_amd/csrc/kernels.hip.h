@@ -94,6 +94,38 @@ struct LongRow { int32_t row, slot0, nslots, pad; };
 
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+// (tools builds: cache policy bits of phase 2's P / slot loads and of phase 1's P stores, -DSH_P2_P_POL / SH_P2_S_POL / SH_P1_ST_POL =
+// 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0)
+#define SH_POL_STR_(n) SH_POL_STR_##n
+#define SH_POL_STR(n) SH_POL_STR_(n)
+#define SH_POL_STR_0 ""
+#define SH_POL_STR_1 " nt"
+#define SH_POL_STR_2 " sc1"
+#define SH_POL_STR_3 " sc0 sc1"
+#define SH_POL_STR_4 " sc0"
+#ifndef SH_P2_P_POL
+#define SH_P2_P_POL 0
+#endif
+#ifndef SH_P2_S_POL
+#define SH_P2_S_POL 0
+#endif
+#ifndef SH_P1_ST_POL
+#define SH_P1_ST_POL 0
+#endif
+// read-once stream words (tools builds, -DSH_P1_NT: a non-temporal load, so that the stream does not push the x tiles out of L2)
+template <class W>
+__device__ __forceinline__ W stream_load(const W *p) {
+#ifdef SH_P1_NT
+  W w;
+  if constexpr (sizeof(W) == 16) { const v4u32 t = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(p)); __builtin_memcpy(&w, &t, 16); }
+  else if constexpr (sizeof(W) == 8) { const v2u32 t = __builtin_nontemporal_load(reinterpret_cast<const v2u32 *>(p)); __builtin_memcpy(&w, &t, 8); }
+  else if constexpr (sizeof(W) == 4) { const uint32_t t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); __builtin_memcpy(&w, &t, 4); }
+  else { const uint16_t t = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(p)); __builtin_memcpy(&w, &t, 2); }
+  return w;
+#else
+  return *p;
+#endif
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
 // outstanding global load (s_waitcnt vmcnt(0)), which would serialise the register prefetch
@@ -839,8 +871,8 @@ __device__ __forceinline__ void tiled_phase1_chunk(
 #pragma unroll
       for (int k = 0; k < U; k++) {
         const int g = min(gbase + k * TBS, le - 1);
-        vw[k] = tval[g];
-        c[k] = tcol2[g];
+        vw[k] = stream_load(&tval[g]);
+        c[k] = stream_load(&tcol2[g]);
         // the wave's 64 groups are one block of obase[] (chunks start on block boundaries): a scalar load
         ob[k] = obase[ch.ob0 + __builtin_amdgcn_readfirstlane(min((gbase + k * TBS - gs) >> 6, last_blk))];
       }
@@ -866,8 +898,15 @@ __device__ __forceinline__ void tiled_phase1_chunk(
           }
           if (valid && !folds) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+#if SH_P1_ST_POL != 0
+            {
+              v4u32 pw = {to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3])};
+              asm volatile("global_store_dwordx4 %0, %1, off" SH_POL_STR(SH_P1_ST_POL) : : "v"(P + ob[k] + 4u * rank), "v"(pw) : "memory");
+            }
+#else
             *reinterpret_cast<uint4 *>(P + ob[k] + 4u * rank) =
                 make_uint4(to_bits<T>(pr[0]), to_bits<T>(pr[1]), to_bits<T>(pr[2]), to_bits<T>(pr[3]));
+#endif
           }
         }
       }
@@ -915,9 +954,9 @@ __device__ __forceinline__ void tiled_phase1_chunk(
     auto load = [&](int sid, SWord (&vw)[NV], uint4 (&c)[2], uint32_t &d) {
       const int q = min(sid, s1 - 1);
 #pragma unroll
-      for (int k = 0; k < NV; k++) vw[k] = sval[(size_t)q * NV + k];
-      c[0] = scol[(size_t)q * 2];
-      c[1] = scol[(size_t)q * 2 + 1];
+      for (int k = 0; k < NV; k++) vw[k] = stream_load(&sval[(size_t)q * NV + k]);
+      c[0] = stream_load(&scol[(size_t)q * 2]);
+      c[1] = stream_load(&scol[(size_t)q * 2 + 1]);
       d = gdest[q - sbase];
     };
     const int lane = tid & 63;
@@ -1028,10 +1067,10 @@ static __global__ void tiled_mark_dead(const int32_t *__restrict__ ptab, const u
 // the single hand-placed wait is phase2_wait_all() at the top of the loop, whose operand list
 // ties every prefetch register to it so that no use can be scheduled above it.
 __device__ __forceinline__ void async_load(v4u32 &dst, const void *addr) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off" SH_POL_STR(SH_P2_P_POL) : "=v"(dst) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ void async_load(v2u32 &dst, const void *addr) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" SH_POL_STR(SH_P2_S_POL) : "=v"(dst) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");

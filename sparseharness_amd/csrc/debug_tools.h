@@ -341,3 +341,5 @@ extern "C" int sh_debug_set_P(sh_engine *e, sh_csr *m, uint64_t address) {
   m->d_P = (uint32_t *)(uintptr_t)address;
   return SH_OK;
 }
+// (slab experiments, tools/slab_probe.py) words of the matrix's product array, for a host-side bounds check before matrices share one
+extern "C" int64_t sh_debug_p_len(const sh_csr *m) { return m && m->plan == PLAN_TILED ? m->p_len : -1; }

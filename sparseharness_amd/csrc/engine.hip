@@ -653,8 +653,8 @@ int sh_csr_upload_ex(sh_engine *e, int64_t rows, int64_t cols, int64_t nnz, cons
     td_n = td.n_pslot; PLAN_ARRAY(m->d_pslot, td.pslot, th.pslot, 2, SLACK_WIDE);
     td_n = td.n_obase; PLAN_ARRAY(m->d_obase, td.obase, th.obase, 4, SLACK_WIDE);
     DEV_ARRAY(m->d_P, (const uint32_t *)nullptr, (size_t)std::max<int64_t>(m->p_len, 4) * 4, 16);
-    if (m->built_on_device) { m->d_lrp = (int32_t *)td.lrp; td.lrp = nullptr; *acct += td.n_lrp * 4; }
-    else DEV_ARRAY(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, 0);
+    if (m->built_on_device) { m->d_lrp = (int32_t *)td.lrp; td.lrp = nullptr; *acct += td.n_lrp * 4 + 16; }
+    else DEV_ARRAY(m->d_lrp, th.lrp.data(), th.lrp.size() * 4, 16);   // (+16: see plan_gpu.hip)
     if (m->n_tlong) {
       DEV_ARRAY(m->d_tlong, th.heavy.data(), th.heavy.size() * sizeof(LongRow), 0);
       DEV_ARRAY(m->d_tpartial, (const uint32_t *)nullptr, (size_t)th.n_partials * 4, 16);

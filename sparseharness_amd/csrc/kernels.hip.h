@@ -270,20 +270,28 @@ template <int NT, int NNZ_CAP> struct ReduceScratch {
   uint32_t se8[NNZ_CAP / (RL_SHORT + 1) + 1];
   uint32_t se64[NNZ_CAP / (RL_MID + 1) + 1];
   uint16_t lstB[NNZ_CAP / (RL_WAVE + 1) + 1];
-  int32_t cnt[8];   // two sets of {n8, n64, nB, -}: the wave-specialised phase 2 alternates them
+  int32_t cnt[8];   // two sets of {n8, n64, nB, next 8-lane row to hand out}: the wave-specialised phase 2 alternates them
   uint32_t wred[NT / 64];
 };
 
 // `tid` in [0, NT) numbers the threads that take part (all of them hit the barriers inside);
 // `cnt` are the three list counters, zeroed before the barrier that published prod[].
-template <class SR, int NT, int NNZ_CAP>
+// RAW (phase 2 of the tiled plan): rp[] holds the light row offsets as they lie in device memory -- bit 31 = the row is
+// produced elsewhere, the rest an offset that `raw_base` turns into an offset into prod[] -- because the words are put
+// there by the loader waves, 16 bytes at a time, untouched (see tiled_phase2_run).
+template <class SR, int NT, int NNZ_CAP, bool RAW = false>
 __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t *rp, int nr, int r0,
                                             ReduceScratch<NT, NNZ_CAP> &sc, int32_t *cnt, const int tid,
                                             const uint32_t *__restrict__ y,
                                             typename SR::T alpha, typename SR::T beta, bool use_y,
                                             uint32_t *__restrict__ out, const StepDev &st,
-                                            uint32_t *stage = nullptr, uint64_t *prof = nullptr) {
+                                            uint32_t *stage = nullptr, uint64_t *prof = nullptr, uint32_t raw_base = 0u) {
   using T = typename SR::T;
+  auto offset_word = [&](int row) -> uint32_t {   // the row's offset in the encoding of the comment above RP_SKIP
+    const uint32_t w = (uint32_t)rp[row];
+    if (!RAW) return w;
+    return ((w & 0x7FFFFFFFu) - raw_base) | ((w >> 31) ? (uint32_t)RP_SKIP : 0u);
+  };
   // stage != nullptr (workgroup-uniform): the row's dot goes to stage[row] in LDS and the caller
   // applies the epilogue later in a coalesced pass (used when the epilogue reads y / prev: those
   // loads would otherwise sit, one row at a time, in the middle of the reduction)
@@ -308,8 +316,8 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
 #pragma unroll
     for (int k = 0; k < R1; k++) {
       const int row = min(row0 + k * NT, nr);   // (rp[nr] is the last offset: a row past the end comes out empty)
-      a[k] = (uint32_t)rp[row];
-      b[k] = (uint32_t)rp[min(row + 1, nr)];
+      a[k] = offset_word(row);
+      b[k] = offset_word(min(row + 1, nr));
     }
     int s[R1], len1[R1];
     bool one[R1];
@@ -361,26 +369,11 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
   lds_barrier();
   SH_STAT(const uint64_t pf_m1 = __builtin_amdgcn_s_memtime(); if (prof) prof[0] += pf_m1 - pf_m0;)
   const int n8 = cnt[0], n64 = cnt[1], nB = cnt[2];
-  for (int idx = tid >> 3; idx < n8; idx += NT / 8) {
-    const int row = sc.lst8[idx], l = tid & 7;
-    const uint32_t se = sc.se8[idx];
-    const int e = (int)(se >> 16);
-    T acc = SR::identity();
-    for (int j = (int)(se & 0xFFFFu) + l; j < e; j += 8 * RL_BATCH8) {
-      uint32_t v[RL_BATCH8];
-#pragma unroll
-      for (int k = 0; k < RL_BATCH8; k++)
-        v[k] = prod[j + 8 * k];   // (unclamped: see RL_PAD)
-#pragma unroll
-      for (int k = 0; k < RL_BATCH8; k++)
-        if (j + 8 * k < e)
-          acc = SR::add(acc, from_bits<T>(v[k]));
-    }
-    acc = sum_to_last_of_8<SR>(acc);
-    if (l == 7)
-      emit(row, acc);
-  }
-  SH_STAT(const uint64_t pf_m2 = __builtin_amdgcn_s_memtime(); if (prof) prof[2] += pf_m2 - pf_m1;)
+  // The 64-lane rows first, one per wave in list order; then the 8-lane rows, eight at a time to whichever wave asks next
+  // (cnt[3]: an LDS counter, zero at the barrier above) -- a wave that has just summed a row of a thousand products takes
+  // fewer of them.  Dealt out by position the waves with a long row were what a bin waited for: wave 0 spent 3.9 K cycles
+  // of a bin on its 8-lane rows and 2.7 K on its 64-lane row, seven of the twelve waves had no long row at all.  Which
+  // wave sums a row does not change the sum.
   for (int idx = tid >> 6; idx < n64; idx += NT / 64) {
     const int row = sc.lst64[idx], l = tid & 63;
     const uint32_t se = sc.se64[idx];
@@ -400,12 +393,41 @@ __device__ inline void reduce_rows_from_lds(const uint32_t *prod, const int32_t 
     if (l == 63)
       emit(row, acc);
   }
-  SH_STAT(if (prof) prof[3] += __builtin_amdgcn_s_memtime() - pf_m2;)
+  SH_STAT(const uint64_t pf_m2 = __builtin_amdgcn_s_memtime(); if (prof) prof[3] += pf_m2 - pf_m1;)
+  for (;;) {
+    int first = 0;
+    if ((tid & 63) == 0)
+      first = atomicAdd(&cnt[3], 8);
+    first = __builtin_amdgcn_readfirstlane(first);   // (lane 0 of the wave is always active here)
+    if (first >= n8)
+      break;
+    const int idx = first + ((tid & 63) >> 3), l = tid & 7;
+    if (idx < n8) {
+      const int row = sc.lst8[idx];
+      const uint32_t se = sc.se8[idx];
+      const int e = (int)(se >> 16);
+      T acc = SR::identity();
+      for (int j = (int)(se & 0xFFFFu) + l; j < e; j += 8 * RL_BATCH8) {
+        uint32_t v[RL_BATCH8];
+#pragma unroll
+        for (int k = 0; k < RL_BATCH8; k++)
+          v[k] = prod[j + 8 * k];   // (unclamped: see RL_PAD)
+#pragma unroll
+        for (int k = 0; k < RL_BATCH8; k++)
+          if (j + 8 * k < e)
+            acc = SR::add(acc, from_bits<T>(v[k]));
+      }
+      acc = sum_to_last_of_8<SR>(acc);
+      if (l == 7)
+        emit(row, acc);
+    }
+  }
+  SH_STAT(if (prof) prof[2] += __builtin_amdgcn_s_memtime() - pf_m2;)
   for (int idx = 0; idx < nB; idx++) {   // nB is workgroup-uniform
     const int row = sc.lstB[idx];
-    const int e = rp[row + 1] & RP_MASK;
+    const int e = (int)(offset_word(row + 1) & RP_MASK);
     T acc = SR::identity();
-    for (int j = (rp[row] & RP_MASK) + tid; j < e; j += NT)
+    for (int j = (int)(offset_word(row) & RP_MASK) + tid; j < e; j += NT)
       acc = SR::add(acc, from_bits<T>(prod[j]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -1075,6 +1097,18 @@ __device__ __forceinline__ void async_load(v2u32 &dst, const void *addr) {
 __device__ __forceinline__ void async_load(uint32_t &dst, const void *addr) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
 }
+// The same from a wave-uniform base (a scalar register pair) plus a 32-bit byte offset per lane: no 64-bit address per lane to
+// compute -- phase 2 is bound by the instructions its waves issue, and a loader step spent a quarter of its on addresses.
+__device__ __forceinline__ void async_load_at(v4u32 &dst, const void *sbase, uint32_t byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" SH_POL_STR(SH_P2_P_POL) : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void async_load_at(v2u32 &dst, const void *sbase, uint32_t byte_off) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" SH_POL_STR(SH_P2_S_POL) : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void async_load_at(uint32_t &dst, const void *sbase, uint32_t byte_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+}
+struct UniformAt { const void *base; uint32_t off; };   // a wave-uniform base and a lane's byte offset
 
 // ---------------------------------------------------------------------------------------------
 // Phase 2, wave-specialised (default).  One 1024-thread workgroup per CU; waves 0-3 are LOADERS,
@@ -1113,7 +1147,8 @@ static_assert(TBIN / 4 <= RL_WAVE, "light rows must not reach the workgroup-wide
 // LDS of the phase-2 role
 struct P2Lds {
   uint32_t prod[2][TBIN + RL_PAD];   // [TBIN]: where the loaders drop padding products; the rest: see RL_PAD
-  int32_t rp[2][TBIN_ROWS + 1];
+  // the light row offsets of a bin, raw, from the 16-byte boundary at or below the bin's first row (the loaders copy them)
+  alignas(16) int32_t rp[2][TBIN_ROWS + 12];   // (the last four words: where a loader thread without a part of the bin's offsets drops its words)
   uint32_t dots[TBIN_ROWS];
   ReduceScratch<P2S_RD, TBIN> sc;
 };
@@ -1185,19 +1220,20 @@ __device__ __forceinline__ void tiled_phase2_run(
       return *reinterpret_cast<const RowBinL *>(reinterpret_cast<const char *>(bins + (b0 + min(j, nb - 1) * stride)) + offsetof(RowBin, gb0));
     };
     auto record_of = [&](const RowBinL &bn, int quarter, int k) -> uint4 {
-      const int nblk = max((bn.n / 4 + 63) / 64, 1);
-      const int blk = min(quarter * (P2S_Q / 64) + k * (P2S_LD / 64) + wave, nblk - 1);   // wave-uniform: a scalar load
-      return gblk[bn.gb0 + blk];
+      const int last_blk = max((int)((((uint32_t)bn.n >> 2) + 63u) >> 6), 1) - 1;
+      const uint32_t blk = (uint32_t)min(quarter * (P2S_Q / 64) + k * (P2S_LD / 64) + wave, last_blk);   // wave-uniform: a scalar load
+      // (a 32-bit unsigned byte offset from the table's base: one s_load with a scalar offset, no 64-bit address to form)
+      return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(gblk) + (((uint32_t)bn.gb0 + blk) << 4));
     };
-    auto ptab_index = [&](const RowBinL &bn, const uint4 rec) -> const int32_t * {
+    auto ptab_index = [&](const RowBinL &bn, const uint4 rec) -> UniformAt {
       // pieces started at or before this lane's group = (started before the block) + (bits of the mask up to the lane's).
       // The mask is shifted down by one on the SCALAR unit so that mbcnt -- bits below the lane -- counts the lane's own
       // bit too; what falls off (bit 0: the block's first group starts a piece) joins the base.  Two vector
       // instructions per group instead of seven.
       const uint64_t m = ((uint64_t)rec.y << 32 | rec.x) >> 1;
-      const int base = max((int)rec.z + (int)(rec.x & 1u) - 1, 0);
+      const uint32_t base1 = max(rec.z + (rec.x & 1u), 1u);   // (one more than the index of the piece the block's first group lies in)
       const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      return ptab + bn.pt0 + base + (int)upto;
+      return UniformAt{ptab + bn.pt0 - 1, (upto + base1) * 4u};
     };
     // The records of a step are fetched one step before its piece words are requested (a scalar load takes a few
     // hundred cycles; asked for and used in the same step it cost 2 us per bin): rec[] always holds the records
@@ -1211,7 +1247,10 @@ __device__ __forceinline__ void tiled_phase2_run(
     auto issue_gs = [&](const RowBinL &bn, uint32_t (&g)[P2S_K]) {
 #pragma unroll
       for (int k = 0; k < P2S_K; k++)
-        async_load(g[k], ptab_index(bn, rec[k]));
+      {
+        const UniformAt at = ptab_index(bn, rec[k]);
+        async_load_at(g[k], at.base, at.off);
+      }
     };
     auto issue_ps = [&](const RowBinL &bn, int quarter, const uint32_t (&g)[P2S_K], v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K]) {
       const int n4 = max(bn.n / 4, 1);
@@ -1221,7 +1260,7 @@ __device__ __forceinline__ void tiled_phase2_run(
 #if defined(SH_DBG_P2) && (SH_DBG_P2 & 2)   // tools builds (wrong results): the slot words of a bin come out of one line
         async_load(s[k], S4 + (tid & 15));
 #else
-        async_load(s[k], S4 + min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1));
+        async_load_at(s[k], S4, (uint32_t)min(quarter * P2S_Q + k * P2S_LD + tid, n4 - 1) * 8u);
 #endif
         // (clamped: a stale register must not fault)
 #if defined(SH_DBG_P2) && (SH_DBG_P2 & 1)   // tools builds (wrong results): P read bin-major, i.e. sequentially
@@ -1232,7 +1271,7 @@ __device__ __forceinline__ void tiled_phase2_run(
         // a piece of a dead tile (tiled_mark_dead): the group of identity words behind the last product
         if (SR::has_absorbing && (int32_t)g[k] == PIECE_DEAD) pg = last_group + 1;
 #endif
-        async_load(p[k], P4 + pg);
+        async_load_at(p[k], P4, (uint32_t)pg * 16u);   // (P < 4 GB: checked at upload)
       }
     };
     auto wait8 = [&](v4u32 (&p)[P2S_K], v2u32 (&s)[P2S_K], uint32_t (&g)[P2S_K]) {
@@ -1264,6 +1303,28 @@ __device__ __forceinline__ void tiled_phase2_run(
         img[min(s3, (uint32_t)TBIN)] = p[k].w;
       }
     };
+    // The light row offsets of the bin being streamed (needed by its reduction, one bin later): words [r0 & ~3, r0 + nr]
+    // of row_ptr[], one to three 16-byte loads per loader thread in step 0 -- issued in FRONT of the step's other loads, so
+    // that the unchanged s_waitcnt vmcnt(8) of step 1 covers them (loads return in order) -- and stored untouched in step 1.
+    constexpr int P2S_RO = (TBIN_ROWS + 8 + 4 * P2S_LD - 1) / (4 * P2S_LD);   // 16-byte loads per loader thread: 3
+    v4u32 ro[P2S_RO];
+    auto rows_of = [&](int j) -> int2 {   // (r0, nr) of the workgroup's j-th bin: one scalar load
+      return *reinterpret_cast<const int2 *>(bins + (b0 + min(j, nb - 1) * stride));
+    };
+    auto issue_ro = [&](const int2 rn) {
+      const int last4 = ((rn.x & 3) + rn.y) & ~3;   // the 16-byte group of the bin's last offset (row nr)
+#pragma unroll
+      for (int k = 0; k < P2S_RO; k++)
+        async_load_at(ro[k], row_ptr + (rn.x & ~3), (uint32_t)min(4 * tid + 4 * P2S_LD * k, last4) * 4u);
+    };
+    auto store_ro = [&](int32_t *dst, const int2 rn) {
+      const int last = (rn.x & 3) + rn.y;
+#pragma unroll
+      for (int k = 0; k < P2S_RO; k++) {
+        const int i4 = 4 * tid + 4 * P2S_LD * k;
+        *reinterpret_cast<v4u32 *>(dst + (i4 <= last ? i4 : TBIN_ROWS + 8)) = ro[k];   // (branch-free, as the scatter)
+      }
+    };
     RowBinL cur = lbin_at(0), nxt = lbin_at(1), nxt2 = lbin_at(2);
     // step q + d (d = 2, 3) seen from step s of the current bin: which bin, which step in it
     auto bin_of = [&](int s_plus_d) -> const RowBinL & {
@@ -1277,8 +1338,9 @@ __device__ __forceinline__ void tiled_phase2_run(
 #pragma unroll
       for (int k = 0; k < P2S_K; k++) {
         const RowBinL &b1 = bin_of(1);
-        g[0][k] = (uint32_t)*ptab_index(cur, record_of(cur, 0, k));
-        g[1][k] = (uint32_t)*ptab_index(b1, record_of(b1, 1 % P2S_NS, k));
+        const UniformAt a0 = ptab_index(cur, record_of(cur, 0, k)), a1 = ptab_index(b1, record_of(b1, 1 % P2S_NS, k));
+        g[0][k] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(a0.base) + a0.off);
+        g[1][k] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(a1.base) + a1.off);
       }
       issue_ps(cur, 0, g[0], p[0], sl[0]);
       fetch_rec(bin_of(2), 2 % P2S_NS);
@@ -1295,6 +1357,11 @@ __device__ __forceinline__ void tiled_phase2_run(
           const int a = s & 1;
           SH_TIMED(pf_wait, wait8(p[a], sl[a], g[a]))      // P/S(q) and the piece words of q+2 have landed
           scatter(img, cur, s, p[a], sl[a]);
+          if (s == 0) issue_ro(rows_of(j));
+          if (s == 1) {
+            asm volatile("" : "+v"(ro[0]), "+v"(ro[1]), "+v"(ro[2]));   // (landed: older than what this step's wait let through)
+            store_ro(rp[j & 1], rows_of(j));
+          }
           issue_gs(bin_of(s + 3), g[a ^ 1]);                          // piece words of step q+3 (records fetched a step ago)
           fetch_rec(bin_of(s + 4), (s + 4) % P2S_NS);                 // records of step q+4
           issue_ps(bin_of(s + 2), (s + 2) % P2S_NS, g[a], p[a], sl[a]);   // P/S(q+2)
@@ -1321,13 +1388,10 @@ __device__ __forceinline__ void tiled_phase2_run(
     SH_STAT(uint64_t pf_bar = 0, pf_red = 0, pf_in[4] = {0, 0, 0, 0}; const uint64_t pf_t0 = __builtin_amdgcn_s_memtime();)
     for (int j = 0; j <= nb; j++) {
       const RowBin cur = bin_at(j);
-      // row offsets of the bin being streamed now (needed by the next reduction)
-      uint32_t rr[P2S_RPU];
-      if (j < nb) {
-#pragma unroll
-        for (int k = 0; k < P2S_RPU; k++)
-          rr[k] = (uint32_t)row_ptr[cur.r0 + min(rt + k * P2S_RD, cur.nr)];
-      }
+      // (the row offsets of the bin being streamed now reach rp[j & 1] through the LOADER waves: loaded by a reducer they had
+      // to be waited for behind the reduction, and that wait -- s_waitcnt vmcnt(0): the counter cannot tell the rows' stores
+      // from the loads in front of them -- drained every store of the bin's rows, ~2.5 K cycles per bin of the waves that set
+      // the kernel's pace: profiles/r04_phase2_role_profile.log)
       int32_t *cnt = sc.cnt + 4 * (j & 1);
       if (j >= 1) {
         // the y / previous-vector words of the rows this lane finishes below are requested now, so that their latency
@@ -1351,15 +1415,20 @@ __device__ __forceinline__ void tiled_phase2_run(
             }
           }
         }
-        SH_TIMED(pf_red, reduce_rows_from_lds<SR, P2S_RD, TBIN>(prod[(j - 1) & 1], rp[(j - 1) & 1], prev.nr, prev.r0, sc, cnt, rt, y,
-                                               alpha, beta, use_y, out, st, staged ? dots : nullptr SH_STAT(, pf_in)))   // contains MID
+        const int32_t *rpp = rp[(j - 1) & 1] + (prev.r0 & 3);   // (row 0 of the bin inside the aligned copy)
+#ifdef SH_STATS
+        uint64_t *const pf_arg = pf_in;
+#else
+        uint64_t *const pf_arg = nullptr;
+#endif
+        SH_TIMED(pf_red, (reduce_rows_from_lds<SR, P2S_RD, TBIN, true>(prod[(j - 1) & 1], rpp, prev.nr, prev.r0, sc, cnt, rt, y,
+                                               alpha, beta, use_y, out, st, staged ? dots : nullptr, pf_arg, (uint32_t)prev.csr0)))   // contains MID
         if (staged) {
           lds_barrier();   // MID2
-          const int32_t *rpp = rp[(j - 1) & 1];
 #pragma unroll
           for (int k = 0; k < P2S_RPU; k++) {
             const int i = rt + k * P2S_RD;
-            if (i < prev.nr && !(rpp[i] & RP_SKIP))
+            if (i < prev.nr && rpp[i] >= 0)   // (bit 31: a heavy row, written before the first bin)
               finish_row_loaded<SR>(prev.r0 + i, from_bits<typename SR::T>(dots[i]), yw[k], same_words ? yw[k] : pw[k], alpha, beta,
                                     use_y, out, st);
           }
@@ -1375,14 +1444,6 @@ __device__ __forceinline__ void tiled_phase2_run(
       }
       if (rt < 4)
         sc.cnt[4 * ((j + 1) & 1) + rt] = 0;   // the other set: last read before the previous END
-      if (j < nb) {
-#pragma unroll
-        for (int k = 0; k < P2S_RPU; k++)
-          if (rt + k * P2S_RD <= cur.nr) {   // light row offsets; bit 31 = heavy row (skipped by the reduction)
-            const uint32_t v = rr[k];
-            rp[j & 1][rt + k * P2S_RD] = (int32_t)((v & 0x7FFFFFFFu) - (uint32_t)cur.csr0) | ((v >> 31) ? RP_SKIP : 0);
-          }
-      }
       SH_TIMED(pf_bar, lds_barrier())     // END
       report(j);
       prev = cur;

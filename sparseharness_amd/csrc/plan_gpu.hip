@@ -682,7 +682,7 @@ int build_tiled_plan_gpu(hipStream_t stream, int64_t rows, int64_t cols, int64_t
   PHASE("  runs, roles, scans");
   // lrp (a final array) and the row bins (host: a greedy cut is sequential)
   D.n_lrp = (size_t)rows + 1;
-  GT(hipMalloc((void **)&D.lrp, D.n_lrp * 4));
+  GT(hipMalloc((void **)&D.lrp, D.n_lrp * 4 + 16));   // (+16: phase 2 copies the offsets of a bin in 16-byte groups, the last one may reach past the array)
   LAUNCH(k_lrp, rows + 1, d_rp, repscan, rows, heavy_thr, D.lrp);
   H.lrp.resize((size_t)rows + 1);
   GT(hipMemcpyAsync(H.lrp.data(), D.lrp, D.n_lrp * 4, hipMemcpyDeviceToHost, stream));

@@ -209,14 +209,14 @@ static __global__ void report_all_pieces(StepDev st) {
 // only on that row's length, so one long row inside a block of short ones
 // never serialises the workgroup and a row's summation order is the same
 // under every plan:
-//   len <= 24    1 lane, sequential in stored order
+//   len <= 40    1 lane, sequential in stored order
 //   len <= 256   8 lanes  (stride-8 partial sums, then a DPP tree into the group's last lane)
 //   len <= 4096  64 lanes (stride-64 partial sums, then a DPP tree into lane 63)
 //   longer       the whole workgroup (stride-NT sums, wave trees, then waves in order)
 // Rows are classified by one pass that finishes the short ones on the spot
 // and appends the others to three LDS work lists.
 #ifndef SH_RL_SHORT
-#define SH_RL_SHORT 24
+#define SH_RL_SHORT 40   // (24 until the 8-lane rows were handed out on demand: 189.6 -> 186 us for phase 2 at 40, the same at 48; profiles/r04_ab_loader_addresses_rowptr_dynamic_rows.log)
 #endif
 constexpr int RL_SHORT = SH_RL_SHORT, RL_MID = 256, RL_WAVE = 4096;
 #ifndef SH_RL_BATCH

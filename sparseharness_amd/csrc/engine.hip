@@ -991,6 +991,18 @@ static int launch_spmv(sh_engine *e, const sh_csr *A, const sh_vec *x, const sh_
                       "reducers total %.0f, in barriers %.0f (%.1f %%), reducing %.0f (one-lane pass %.0f, 8-lane rows %.0f, 64-lane rows %.0f)\n",
               G, a[3], a[0], a[1], 100 * a[1] / a[0], a[2], 100 * a[2] / a[0], a[0] - a[1] - a[2], a[4], a[5], 100 * a[5] / a[4], a[6], a[8], a[9], a[10]);
     }
+    if (getenv("SH_STATS_DUMP") && A->n_bins > 0) {   // the same per reducer wave: who a bin waits for
+      std::vector<uint64_t> pw(256 * 12 * 4);
+      (void)hipMemcpyFromSymbol(pw.data(), HIP_SYMBOL(g_p2_wave), pw.size() * 8);
+      const int G = std::min(A->n_bins, 256);
+      fprintf(stderr, "[stats] phase 2 reducer waves (K cycles: at barriers / classifying pass / cooperative rows / total):");
+      for (int w = 0; w < 12; w++) {
+        double a[4] = {0, 0, 0, 0};
+        for (int g = 0; g < G; g++) for (int k = 0; k < 4; k++) a[k] += (double)pw[((size_t)g * 12 + w) * 4 + k] / G;
+        fprintf(stderr, "  w%d %.0f/%.0f/%.0f/%.0f", w, a[0] / 1e3, a[1] / 1e3, a[2] / 1e3, a[3] / 1e3);
+      }
+      fprintf(stderr, "\n");
+    }
     if (getenv("SH_STATS_DUMP") && p1_stats) {
       const int nch = A->n_chunks;
       std::vector<uint64_t> hs((size_t)nch * 5);

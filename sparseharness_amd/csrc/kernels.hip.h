@@ -775,6 +775,7 @@ SH_STAT(__device__ uint64_t *g_p1_stats;)
 // barriers, [3] bins, [4] reducer total, [5] reducer in barriers, [6] reducer in the reduction proper, [7] bins,
 // [8..10] reducer in the one-lane pass / the 8-lane rows / the 64-lane rows
 SH_STAT(__device__ uint64_t g_p2_prof[256 * 16];)
+SH_STAT(__device__ uint64_t g_p2_wave[256 * 12 * 4];)   // per reducer wave: cycles at barriers, in the classifying pass, in the cooperative rows, in all
 #ifdef SH_STATS
 #define SH_TIMED(acc, ...) { const uint64_t pf_a = __builtin_amdgcn_s_memtime(); __VA_ARGS__; acc += __builtin_amdgcn_s_memtime() - pf_a; }
 #else
@@ -1449,6 +1450,7 @@ __device__ __forceinline__ void tiled_phase2_run(
       prev = cur;
     }
     SH_STAT(if (rt == 0) { uint64_t *S = g_p2_prof + (blockIdx.x & 255) * 16; S[4] = __builtin_amdgcn_s_memtime() - pf_t0; S[5] = pf_bar + pf_in[0]; S[6] = pf_red - pf_in[0]; S[7] = (uint64_t)nb; S[8] = pf_in[1]; S[9] = pf_in[2]; S[10] = pf_in[3]; })
+    SH_STAT(if ((rt & 63) == 0) { uint64_t *W = g_p2_wave + ((blockIdx.x & 255) * 12 + (rt >> 6)) * 4; W[0] = pf_bar + pf_in[0]; W[1] = pf_in[1]; W[2] = pf_in[2] + pf_in[3]; W[3] = __builtin_amdgcn_s_memtime() - pf_t0; })
   }
 }
 

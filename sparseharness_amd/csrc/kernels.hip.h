@@ -1116,9 +1116,10 @@ struct UniformAt { const void *base; uint32_t off; };   // a wave-uniform base a
 // waves 4-15 REDUCERS, and the LDS holds two product images:
 //   loaders   stream bin j+1 (P pieces via the piece tables, slots) and scatter it into image (j+1)&1;
 //   reducers  reduce bin j out of image j&1 and write the rows.
-// (Round 4 measured where this kernel's time goes -- profiles/r04_phase2_role_profile.log: the loader waves wait for
-// loads 6-12 % of their cycles and for barriers a third; reading P sequentially changes nothing: the kernel is bound by
-// the instructions and LDS latencies of its CU, not by memory.  The reasoning below is how it got its shape.)
+// (Round 4 measured where this kernel's time goes -- profiles/r04_phase2_role_profile.log, r04_phase2_decoupled_roles_probe.log:
+// while the reducers were the slower role the loader waves waited at barriers, not for loads, and the kernel looked
+// compute-bound; with the reducers out of the way -- batched LDS reads, DPP trees, cooperative rows handed out on demand --
+// it runs at what the reasoning below says: the read requests a CU keeps in flight per memory latency, 8.1 M of them per launch.)
 // Why: a CU sustains only what its miss queue holds per memory latency, so HBM time is lost
 // whenever no wave of the CU has a load to issue.  With every wave alternating between "stream
 // a bin" and "reduce a bin" (spmv_tiled_phase2 above, two workgroups per CU) the two workgroups

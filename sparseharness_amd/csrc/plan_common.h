@@ -183,8 +183,12 @@ static inline void cut_work_items(const int CT, const std::vector<int64_t> &run_
   // (Six rounds per size, every round a fresh process = fresh allocations: 96 K 0.4455, 128 K 0.4360, 160 K 0.4330, 192 K 0.4324,
   // 256 K 0.4349 ms; odd multiples of 1024 entries -- no power-of-two stride between the workgroups' streams -- change nothing:
   // profiles/r03_ab_chunk_sizes_*.log.  Within the +-1 % that the placement of the arrays alone moves the time.)
+  // Round 4, after phase 2's reducers had been rebalanced (same box, twice each, profiles/r04_ab_chunk_sizes_160K.log): 128 K 233.6 / 235.1 us of
+  // phase 1, 160 K 228.2 / 228.7, 192 K 229.6 / 229.4, 224 K 228.8 -> 160 K while the launch keeps 5.5 items per CU.
   const int64_t enough = 6ll * std::max(n_cus, 1);
-  int64_t chunk = opt.chunk > 0 ? opt.chunk : (items_at(131072) >= enough ? 131072 : (items_at(65536) >= enough ? 65536 : 49152));
+  int64_t chunk = opt.chunk > 0 ? opt.chunk
+                  : (2 * items_at(163840) >= 11ll * std::max(n_cus, 1) ? 163840
+                     : (items_at(131072) >= enough ? 131072 : (items_at(65536) >= enough ? 65536 : 49152)));
   chunk = std::max<int64_t>(1024, chunk) & ~int64_t(64 * HSTRIP - 1);   // whole waves of heavy strips
   const bool xcd_order = opt.xcd_order != 0;
   // Which XCD's list a tile's chunks go to.  Uniform columns: tile % 8 (every XCD stages its own eighth of x).

@@ -184,7 +184,8 @@ static inline void cut_work_items(const int CT, const std::vector<int64_t> &run_
   // 256 K 0.4349 ms; odd multiples of 1024 entries -- no power-of-two stride between the workgroups' streams -- change nothing:
   // profiles/r03_ab_chunk_sizes_*.log.  Within the +-1 % that the placement of the arrays alone moves the time.)
   // Round 4, after phase 2's reducers had been rebalanced (same box, twice each, profiles/r04_ab_chunk_sizes_160K.log): 128 K 233.6 / 235.1 us of
-  // phase 1, 160 K 228.2 / 228.7, 192 K 229.6 / 229.4, 224 K 228.8 -> 160 K while the launch keeps 5.5 items per CU.
+  // phase 1, 160 K 228.2 / 228.7, 192 K 229.6 / 229.4, 224 K 228.8 -> 160 K while the launch keeps 5.5 items per CU.  (R-MAT-23, skewed tiles,
+  // stays with its 64 K items: 160 K measured 169.8 us against 174-176, once, inside the spread between boxes.)
   const int64_t enough = 6ll * std::max(n_cus, 1);
   int64_t chunk = opt.chunk > 0 ? opt.chunk
                   : (2 * items_at(163840) >= 11ll * std::max(n_cus, 1) ? 163840
